@@ -1,0 +1,178 @@
+/*
+ * tzddpc.h -- C-ABI of the MI355X (gfx950) TZDDPC hot path.
+ *
+ * The reference (rssalessio/TZDDPC) is pure Python and has no FFI; its boundary for this path is the
+ * Python method surface of class TZDDPC.  Each entry point below names the reference interface it
+ * stands behind (paths relative to the reference repository).  The Python binding that calls these
+ * through ctypes is tzddpc_amd/native.py; INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - all matrices row-major, double precision, caller-owned; the library copies what it keeps and
+ *     never frees caller memory;
+ *   - every function returns 0 on success, a negative tz_status on failure; tz_last_error() gives the
+ *     message of the last failure on the calling thread;
+ *   - one tz_problem belongs to one device; calls on one tz_problem must be serialised by the caller
+ *     (the reference object is not thread-safe either: all state hangs off the TZDDPC instance);
+ *   - batch pointers (xbar0, e0, v, xbar, ...) are HOST pointers when mem == TZ_MEM_HOST and DEVICE
+ *     pointers (e.g. torch tensor .data_ptr()) when mem == TZ_MEM_DEVICE; with device pointers a call
+ *     only enqueues work on the problem's stream (tz_problem_sync / tz_problem_stream to order it).
+ */
+#ifndef TZDDPC_H
+#define TZDDPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TZ_ABI_VERSION 1
+
+typedef enum tz_status {
+  TZ_OK = 0,
+  TZ_ERR_INVALID = -1,   /* bad argument / inconsistent sizes            */
+  TZ_ERR_HIP = -2,       /* HIP runtime error (no device, launch failure) */
+  TZ_ERR_UNSUPPORTED = -3
+} tz_status;
+
+/* per-trajectory solve status (int32 array `status`) */
+enum {
+  TZ_SOLVED = 0,
+  TZ_MAX_ITER = 1,          /* iteration cap hit before the tolerances                              */
+  TZ_NUMERICAL = 2,         /* non-finite iterate / failed factorisation                            */
+  TZ_INFEASIBLE = 3,        /* complementarity exhausted with residual left, or a parameter-only    */
+                            /* constraint violated (e.g. xbar0 + e0 outside X, reference            */
+                            /* tzddpc/tzddpc.py:191-195 at k = 0); the reference raises              */
+                            /* Exception('Problem is unbounded') for both (tzddpc/tzddpc.py:374-375) */
+};
+
+enum { TZ_MEM_HOST = 0, TZ_MEM_DEVICE = 1 };
+
+/* Sparse affine map  out[i] = c0[i] + sum_{e in [ptr[i], ptr[i+1])} val[e] * theta[col[e]]  (CSR). */
+typedef struct tz_affmap {
+  int32_t rows;
+  const int32_t* ptr;   /* rows + 1 */
+  const int32_t* col;
+  const double* val;
+  const double* c0;     /* rows */
+} tz_affmap;
+
+/*
+ * Everything TZDDPC.build_problem / build_problem_simplified fixes at build time
+ * (reference tzddpc/tzddpc.py:132-241, :243-355), already collapsed and equilibrated by the host
+ * (tzddpc_amd/builder.py, tzddpc_amd/tzddpc.py):
+ *
+ *   per trajectory and MPC step the device solves, for parameters (xbar0, e0),
+ *       minimise 1/2 x'P x + q(theta)'x     subject to   G x <= h(theta)
+ *   theta = [ xbar0 | |xbar0| | (c_k, rho^x_k, rho^u_k)_{k<N} ]  with the last block computed on the
+ *   device from e0 by the tube recursion (the numeric content of reference :172-181, :191-192).
+ */
+typedef struct tz_problem_desc {
+  int32_t abi_version;      /* TZ_ABI_VERSION */
+  int32_t n, m, N;          /* dim_x, dim_u, horizon (reference :30-43, :134) */
+  int32_t nz, mi;           /* decision variables, one-sided inequality rows */
+  int32_t ntheta;           /* 2 n + N (2 n + m) */
+  const double* P;          /* nz x nz, symmetric PSD, scaled */
+  const double* G;          /* mi x nz, scaled */
+  tz_affmap q;              /* nz rows  (already times c D)  */
+  tz_affmap h;              /* mi rows  (already times E)    */
+  tz_affmap par;            /* parameter-only rows, feasible iff par_lo <= value <= par_hi */
+  const double* par_lo;
+  const double* par_hi;
+  /* objective:  (1/2 x'Px + q'x) / cost_scale + r0 + r1'xbar0 + xbar0'R2 xbar0  == the value
+   * cvxpy's problem.solve() returns (reference :367)                                            */
+  double cost_scale;
+  double r0;
+  const double* r1;         /* n */
+  const double* R2;         /* n x n */
+  const double* Dz;         /* nz: z = Dz .* x  (undo column equilibration) */
+  const double* Phi;        /* (N+1) n x n     xbar = Phi xbar0 + Gam v   (reference :166-170) */
+  const double* Gam;        /* (N+1) n x N m */
+  /* multipliers per row of the two-sided problem the host built (for the active-set report) */
+  int32_t nc_rows;          /* rows of that problem */
+  const int32_t* row_of;    /* mi: which of those rows an inequality row belongs to */
+  /* tube constants (reference :119-128 after reduce(1); :175, :181) */
+  const double* CK;         /* n x n  center of MdataK = Ahat + Bhat K */
+  const double* DK;         /* n x n  sum_i |G_i| of MdataK's single-entry generators */
+  const double* K;          /* m x n  theta.K */
+  int32_t pmax;             /* highest power of M_K applied to <e0, 0> */
+  const double* absCKpow;   /* pmax x n x n   |C_K^j| */
+  const double* absKCKpow;  /* pmax x m x n   |K C_K^j| */
+  const int32_t* power;     /* N: the e0 part of Ze_k is M_K^power[k] <e0, 0> (full: k; simplified :292-295) */
+  /* interior-point options */
+  int32_t max_iter;
+  double tol;               /* scaled residual / complementarity tolerance */
+  double reg;               /* static diagonal regularisation of the reduced Newton matrix */
+  double step_frac;         /* fraction of the step to the boundary */
+} tz_problem_desc;
+
+typedef struct tz_problem tz_problem;
+
+/* ABI / device discovery */
+int tz_abi_version(void);
+const char* tz_last_error(void);
+int tz_device_count(int* count);
+
+/* Build-time: upload one problem to `device`.  Stands behind the *result* of
+ * TZDDPC.build_problem / build_problem_simplified (reference tzddpc/tzddpc.py:132, :243), i.e. the
+ * object `self.problem_full` that solve() later consumes. */
+int tz_problem_create(int device, const tz_problem_desc* desc, tz_problem** out);
+int tz_problem_destroy(tz_problem* p);
+
+/* Stream control (plumbing for torch interop): `stream` is a hipStream_t, NULL = library-owned stream. */
+int tz_problem_set_stream(tz_problem* p, void* stream);
+int tz_problem_sync(tz_problem* p);
+
+/*
+ * TZDDPC.solve(xbar0, e0, **kw) for a batch of B independent trajectories
+ * (reference tzddpc/tzddpc.py:357-377; the loop bodies examples/1.double_integrator_sim.py:76-80).
+ *   xbar0, e0 : B x n           (in)
+ *   v         : B x N x m       (out)   == self.variables[0].value
+ *   xbar      : B x (N+1) x n   (out)   == self.variables[1].value
+ *   cost      : B               (out)   == result
+ *   status    : B int32         (out)   see enum above; the Python layer maps != TZ_SOLVED of a
+ *                                       single-trajectory call to the reference's exceptions
+ *   iters     : B int32         (out, may be NULL)
+ *   active    : B x nc_rows uint8 (out, may be NULL)  1 = constraint row active at the optimum
+ */
+int tz_solve_batch(tz_problem* p, int32_t B, const double* xbar0, const double* e0,
+                   double* v, double* xbar, double* cost, int32_t* status, int32_t* iters,
+                   uint8_t* active, int mem);
+
+/*
+ * Closed loop over T steps for B trajectories: the loop of examples/1.double_integrator_sim.py:75-90
+ * (solve -> xbar+ = xbar[1] -> u = K e + v[0] -> x+ = A x + B u + w -> e+ = x+ - xbar+), one launch
+ * sequence per step, no host synchronisation inside.
+ *   x0      : B x n                    initial state (xbar starts at x0, e at 0, :68-70)
+ *   noise   : B x T x n                process noise realisations w_t
+ *   A_true  : n x n, B_true : n x m    plant
+ *   x_traj  : B x (T+1) x n  (out)     u_traj : B x T x m (out)
+ *   cost    : B x T (out, may be NULL) status : B int32 (out) first non-zero step status, sticky
+ */
+int tz_simulate_batch(tz_problem* p, int32_t B, int32_t T, const double* x0, const double* noise,
+                      const double* A_true, const double* B_true,
+                      double* x_traj, double* u_traj, double* cost, int32_t* status, int mem);
+
+/* One closed-loop step on device-resident state (what bench.py times): state buffers are device
+ * pointers owned by the caller: x, xbar, e : B x n (in/out); w : B x n (in); u_out : B x m. */
+int tz_mpc_step(tz_problem* p, int32_t B, double* x, double* xbar, double* e, const double* w,
+                const double* A_true, const double* B_true, double* u_out, double* cost, int32_t* status);
+
+/* Kernel timing with HIP events on the problem's stream (bench.py roofline leg).
+ * kernel ids: 0 = tz_prepare, 1 = tz_ipm, 2 = tz_finish, 3 = tz_plant_step */
+int tz_timing_enable(tz_problem* p, int enable);
+int tz_timing_get(tz_problem* p, int kernel, double* total_ms, int64_t* launches);
+/* algorithmic work of the last tz_ipm launch: MFMA (4x4x4 f64) instructions issued per interior-point
+ * iteration by one trajectory (Gram formation + Cholesky trailing updates), from the static plan. */
+int tz_ipm_plan_info(tz_problem* p, int64_t* mfma_gram_per_iter, int64_t* mfma_chol_per_iter,
+                     int64_t* lds_bytes, int64_t* patch_bytes);
+
+/* Test hook: copy device-side intermediates of trajectory `b` of the last solve to the host.
+ * what: 0 = theta (ntheta), 1 = q (nz), 2 = h (mi), 3 = x (nz), 4 = s (mi), 5 = lambda (mi) */
+int tz_debug_fetch(tz_problem* p, int32_t b, int what, double* out, int32_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TZDDPC_H */

@@ -1,0 +1,436 @@
+"""Build-time assembly of the TZDDPC problem into the data the HIP kernels consume.
+
+Replaces the symbolic construction in reference ``tzddpc/tzddpc.py:132-241`` (``build_problem``)
+and ``:243-355`` (``build_problem_simplified``).  Runs once per ``build_problem`` call on the host
+(numpy); nothing here is on the per-step path.
+
+What the reference does literally -- ``MatrixZonotope * CVXZonotope`` products whose generator
+count grows by (gamma_K + 1) per horizon step -- is collapsed exactly:
+when every generator of ``MdataK`` / ``Mdelta`` has a single non-zero entry (the Girard order-1
+boxes of ``:126-128``), with Delta = sum_i |G_i| (entry-wise),
+
+    M_K * <c, D, [(P_l, b_l)]> = < C_K c, C_K D, [(C_K P_l, b_l)] + [(I, Delta_K(|c| + rad))] >
+    rad = sum_j |D_:j| + sum_l |P_l| b_l                         (interval radius, ``:191``)
+
+so every interval radius is  (a part depending on e0 only, evaluated per step by the HIP kernel
+``tz_prepare``)  +  (a constant from W)  +  (non-negative matrices) x |[xbar_j; v_j]|.  The only
+decision-dependent non-linearity is the component-wise absolute value, handled by epigraph
+variables t_j >= |[xbar_j; v_j]|.  The result is a QP whose matrices are shared by all
+trajectories and all MPC steps; only q, l, u depend -- affinely -- on
+
+    theta = [ xbar0 | |xbar0| | (c_k, rho^x_k, rho^u_k)_{k<N} ]      (the last block from e0)
+
+Decision vector (condensed, xbar eliminated through xbar_k = A^k xbar0 + sum_j A^(k-1-j) B v_j):
+
+    z = [ v (N m) | t (used |.| epigraphs) | s (loss epigraphs) | u_free (only if the loss needs it) ]
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from . import cplite
+from .cplite import Affine, Constraint, Convex, CpliteError
+
+
+class StructureError(NotImplementedError):
+    """Matrix-zonotope generators are not single-entry: needs the general stacked-generator path."""
+
+
+@dataclass
+class TubeConstants:
+    n: int
+    m: int
+    N: int
+    CK: np.ndarray            # center of MdataK  (= Ahat + Bhat K)
+    DK: np.ndarray            # Delta_K   n x n
+    K: np.ndarray             # m x n
+    pmax: int                 # highest power of M_K applied to <e0>
+    absCKpow: np.ndarray      # (pmax, n, n)   |C_K^j|
+    absKCKpow: np.ndarray     # (pmax, m, n)   |K C_K^j|
+    power: np.ndarray         # (N,) int32: Ze_k's e0-part is M_K^power[k] <e0>
+
+
+@dataclass
+class ParametricQP:
+    n: int
+    m: int
+    N: int
+    nz: int
+    nc: int
+    ntheta: int
+    P: np.ndarray
+    A: np.ndarray
+    # affine maps over theta (dense here; the native layer converts to CSR)
+    q0: np.ndarray
+    Qt: np.ndarray            # nz x ntheta
+    l0: np.ndarray
+    Lt: np.ndarray            # nc x ntheta
+    u0: np.ndarray
+    Ut: np.ndarray
+    # pure-parameter rows  pl <= f0 + Ft theta <= pu
+    f0: np.ndarray
+    Ft: np.ndarray
+    pl: np.ndarray
+    pu: np.ndarray
+    # objective constant r0 + r1'xbar0 + xbar0'R2 xbar0
+    r0: float
+    r1: np.ndarray
+    R2: np.ndarray
+    # recovery  xbar = Phi xbar0 + Gam v
+    Phi: np.ndarray
+    Gam: np.ndarray
+    tube: TubeConstants
+    row_names: List[str] = field(default_factory=list)
+    var_names: List[str] = field(default_factory=list)
+    # constants for the literal Ze[1] export (reference returns Ze[1], tzddpc.py:377)
+    n_v: int = 0
+
+    def theta_index(self):
+        n, m, N = self.n, self.m, self.N
+        blk = 2 * n + m
+        return dict(xbar0=lambda i: i, absx0=lambda i: n + i,
+                    c=lambda k, i: 2 * n + k * blk + i,
+                    rx=lambda k, i: 2 * n + k * blk + n + i,
+                    ru=lambda k, j: 2 * n + k * blk + 2 * n + j)
+
+
+class _Box:
+    """Axis-aligned box half-widths  b = b0 + Bt t  (t = stacked |[xbar_j; v_j]|, j < N)."""
+    __slots__ = ("b0", "Bt")
+
+    def __init__(self, b0, Bt):
+        self.b0, self.Bt = b0, Bt
+
+
+class _Z:
+    """< c, D, [(P_l, box_l)] > with numeric c, D, P_l."""
+    __slots__ = ("c", "D", "layers")
+
+    def __init__(self, c, D, layers):
+        self.c, self.D, self.layers = c, D, layers
+
+    def radius(self, L, nt):
+        b0 = np.abs(L @ self.D).sum(axis=1)
+        Bt = np.zeros((L.shape[0], nt))
+        for P, box in self.layers:
+            M = np.abs(L @ P)
+            b0 = b0 + M @ box.b0
+            Bt = Bt + M @ box.Bt
+        return b0, Bt
+
+
+def _apply_MK(CK, DK, Z: _Z, nt) -> _Z:
+    n = CK.shape[0]
+    b0, Bt = Z.radius(np.eye(n), nt)
+    new = _Box(DK @ (np.abs(Z.c) + b0), DK @ Bt)
+    return _Z(CK @ Z.c, CK @ Z.D, [(CK @ P, box) for P, box in Z.layers] + [(np.eye(n), new)])
+
+
+def _minkowski(Z1: _Z, Z2: _Z) -> _Z:
+    return _Z(Z1.c + Z2.c, np.concatenate([Z1.D, Z2.D], axis=1), Z1.layers + Z2.layers)
+
+
+def noise_schedule(N: int, k0: Optional[int]):
+    """For k' = 0..N-1: (start, J) with term2[k'] = sum_{i<=J} M_K^(J-i) Z_noise[start+i]  (literal nesting).
+
+    full (``:183-186``): start 0, J = max(k'-1, 0);  simplified (``:297-300``): start = max(0,k'-k0),
+    J = max(min(k',k0)-1, 0).
+    """
+    out = []
+    for kp in range(N):
+        if k0 is None:
+            out.append((0, max(kp - 1, 0)))
+        else:
+            out.append((max(0, kp - k0), max(min(kp, k0) - 1, 0)))
+    return out
+
+
+def term1_power(N: int, k0: Optional[int]) -> np.ndarray:
+    """power[k]: Ze_k's e0 part is M_K^power[k] <e0>; term1[j] = M_K^(min(j, k0+1)+1) <e0> (``:175,181,292-295``)."""
+    pw = np.zeros(N, dtype=np.int32)
+    for k in range(1, N):
+        j = k - 1
+        pw[k] = (j + 1) if k0 is None else (min(j, k0 + 1) + 1)
+    return pw
+
+
+def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: int,
+                        build_loss: Callable, build_constraints: Optional[Callable],
+                        k0: Optional[int] = None) -> ParametricQP:
+    Ahat = np.asarray(Ahat, float); Bhat = np.asarray(Bhat, float)
+    K = np.atleast_2d(np.asarray(K, float))
+    n, m = Bhat.shape
+    p = n + m
+    nt = N * p
+    W_c = np.asarray(W_c, float).reshape(n); W_G = np.asarray(W_G, float).reshape(n, -1)
+
+    # ---- condensed nominal dynamics (``:166-170``): xbar_k = Phi_k xbar0 + Gam_k v ------------
+    Phi = np.zeros((N + 1, n, n)); Gam = np.zeros((N + 1, n, N * m))
+    Phi[0] = np.eye(n)
+    for k in range(N):
+        Phi[k + 1] = Ahat @ Phi[k]
+        Gam[k + 1] = Ahat @ Gam[k]
+        Gam[k + 1][:, k * m:(k + 1) * m] += Bhat
+
+    # ---- noise chains term2[k'] (e0-independent; numeric centers, boxes affine in t) -----------
+    Z_noise = []
+    for j in range(N):                                                   # ``:176``
+        Bt = np.zeros((n, nt)); Bt[:, j * p:(j + 1) * p] = Dd
+        Z_noise.append(_Z(W_c.copy(), W_G.copy(), [(np.eye(n), _Box(np.zeros(n), Bt))]))
+    term2 = []
+    for start, J in noise_schedule(N, k0):
+        Zn = Z_noise[start]
+        for i in range(1, J + 1):
+            Zn = _minkowski(_apply_MK(CK, DK, Zn, nt), Z_noise[start + i])
+        term2.append(Zn)
+    power = term1_power(N, k0)
+    pmax = int(power.max(initial=0))
+    absCK = np.zeros((max(pmax, 1), n, n)); absKCK = np.zeros((max(pmax, 1), m, n))
+    Mp = np.eye(n)
+    for j in range(max(pmax, 1)):
+        absCK[j] = np.abs(Mp); absKCK[j] = np.abs(K @ Mp)
+        Mp = CK @ Mp
+    tube = TubeConstants(n, m, N, CK.copy(), DK.copy(), K.copy(), pmax, absCK, absKCK, power)
+
+    # per-step noise-side center / radii
+    cn = np.zeros((N, n)); rx0 = np.zeros((N, n)); rxT = np.zeros((N, n, nt)); ru0 = np.zeros((N, m)); ruT = np.zeros((N, m, nt))
+    for k in range(1, N):
+        Zn = term2[k - 1]
+        cn[k] = Zn.c
+        rx0[k], rxT[k] = Zn.radius(np.eye(n), nt)
+        ru0[k], ruT[k] = Zn.radius(K, nt)
+
+    # ---- which |.| epigraphs are needed --------------------------------------------------------
+    used = (np.abs(rxT).sum(axis=(0, 1)) + np.abs(ruT).sum(axis=(0, 1))) > 0      # (nt,)
+    t_var = {}                       # (j, c) -> z index
+    var_names = [f"v[{k},{j}]" for k in range(N) for j in range(m)]
+    nzc = N * m
+    for j in range(N):
+        for c in range(p):
+            if used[j * p + c] and not (j == 0 and c < n):       # |xbar0| is a parameter
+                t_var[(j, c)] = nzc; nzc += 1
+                var_names.append(f"t[{j},{c}]")
+
+    # ---- callbacks on look-alike variables -----------------------------------------------------
+    nsym = N * m + N * m + n                       # [v | u_free | xbar0]
+    sv = slice(0, N * m); su = slice(N * m, 2 * N * m); sp = slice(2 * N * m, nsym)
+    Cv = np.zeros((N * m, nsym)); Cv[:, sv] = np.eye(N * m)
+    v_expr = Affine(Cv, np.zeros(N * m), (N, m))
+    Cu = np.zeros((N * m, nsym)); Cu[:, su] = np.eye(N * m)
+    u_expr = Affine(Cu, np.zeros(N * m), (N, m))
+    Cx = np.zeros(((N + 1) * n, nsym))
+    Cx[:, sv] = Gam.reshape((N + 1) * n, N * m); Cx[:, sp] = Phi.reshape((N + 1) * n, n)
+    xbar_expr = Affine(Cx, np.zeros((N + 1) * n), (N + 1, n))
+    if k0 is None:
+        loss = build_loss(u_expr, xbar_expr)                                        # ``:222``
+        cons = build_constraints(v_expr, xbar_expr) if build_constraints is not None else []   # ``:213``
+    else:
+        loss = build_loss(v_expr, xbar_expr[1:])                                    # ``:336``
+        cons = build_constraints(v_expr, xbar_expr[1:]) if build_constraints is not None else []  # ``:327``
+    if loss is None:
+        raise Exception("Loss function is not defined or is not convex!")
+    loss = cplite.as_convex(loss, nsym)
+    cons = [] if cons is None else list(cons)
+    for idx, c in enumerate(cons):
+        if c is None or not isinstance(c, Constraint):
+            raise Exception(f"Constraint {idx} is not defined or is not convex.")           # ``:215-217``
+
+    # free-u analysis (``:160,222``: u is constrained by nothing)
+    def _uses_u(C):
+        return bool(np.any(C[:, su]))
+
+    def _only_u_homogeneous(e: Affine):
+        return _uses_u(e.C) and not np.any(e.C[:, sv]) and not np.any(e.C[:, sp]) and not np.any(e.d)
+
+    if np.any(loss.lin[su]):
+        raise Exception("Problem is unbounded")     # a linear term in the free variable u
+    need_u = any(_uses_u(c.expr.C) for c in cons)
+    terms = {"sq": [], "ab": [], "mx": []}
+    for kind in ("sq", "ab", "mx"):
+        for w, e in getattr(loss, kind):
+            if w == 0.0:
+                continue
+            if _only_u_homogeneous(e):
+                continue                             # min over free u of a norm of a linear map of u is 0
+            if _uses_u(e.C):
+                need_u = True
+            terms[kind].append((w, e))
+    u_var0 = None
+    if need_u:
+        u_var0 = nzc; nzc += N * m
+        var_names += [f"u[{k},{j}]" for k in range(N) for j in range(m)]
+
+    def z_coef(Crow, nz_now):
+        """symbol coefficients -> (z-part over current nz, xbar0-part)."""
+        zc = np.zeros(nz_now)
+        zc[:N * m] = Crow[sv]
+        if u_var0 is not None:
+            zc[u_var0:u_var0 + N * m] = Crow[su]
+        return zc, Crow[sp]
+
+    # loss epigraph variables
+    epi_specs = []       # (weight, [(Crow, d)], "sum"|"max")
+    for w, e in terms["ab"]:
+        for r in range(e.size):
+            if not np.any(e.C[r]):
+                continue
+            epi_specs.append((w, [(e.C[r], e.d[r])]))
+    for w, e in terms["mx"]:
+        rows_ = [(e.C[r], e.d[r]) for r in range(e.size)]
+        if any(np.any(c) for c, _ in rows_):
+            epi_specs.append((w, rows_))
+    s_var0 = nzc
+    nzc += len(epi_specs)
+    var_names += [f"s[{i}]" for i in range(len(epi_specs))]
+    nz = nzc
+
+    ntheta = 2 * n + N * (2 * n + m)
+    blk = 2 * n + m
+    ix_x0 = lambda i: i
+    ix_ax0 = lambda i: n + i
+    ix_c = lambda k, i: 2 * n + k * blk + i
+    ix_rx = lambda k, i: 2 * n + k * blk + n + i
+    ix_ru = lambda k, j: 2 * n + k * blk + 2 * n + j
+
+    rows = []   # (name, zcoef, lo_c, lo_t, hi_c, hi_t)
+
+    def add_row(name, zc, lo_c, lo_t, hi_c, hi_t):
+        rows.append((name, zc, lo_c, lo_t, hi_c, hi_t))
+
+    zeros_t = lambda: np.zeros(ntheta)
+
+    # ---- tube rows (``:189-209``) --------------------------------------------------------------
+    for k in range(N):
+        for i in range(n):
+            zc = np.zeros(nz); zc[:N * m] = Gam[k][i]
+            tt = np.zeros(nz)
+            th_abs = zeros_t()
+            for (j, c), zi in t_var.items():
+                tt[zi] = rxT[k][i, j * p + c]
+            for c in range(n):
+                th_abs[ix_ax0(c)] = rxT[k][i, c]             # j = 0, xbar part -> |xbar0|
+            base = zeros_t()
+            base[[ix_x0(c) for c in range(n)]] = Phi[k][i]
+            base[ix_c(k, i)] += 1.0
+            rxk = zeros_t(); rxk[ix_rx(k, i)] = 1.0
+            # upper: xbar + c + rad <= xu
+            add_row(f"Xub[{k},{i}]", zc + tt, -np.inf, zeros_t(), xu[i] - cn[k, i] - rx0[k, i], -(base + rxk + th_abs))
+            # lower: xbar + c - rad >= xl
+            add_row(f"Xlb[{k},{i}]", zc - tt, xl[i] - cn[k, i] + rx0[k, i], -(base - rxk - th_abs), np.inf, zeros_t())
+        Kcn = K @ cn[k]
+        for j2 in range(m):
+            zc = np.zeros(nz); zc[k * m + j2] = 1.0
+            tt = np.zeros(nz); th_abs = zeros_t()
+            for (j, c), zi in t_var.items():
+                tt[zi] = ruT[k][j2, j * p + c]
+            for c in range(n):
+                th_abs[ix_ax0(c)] = ruT[k][j2, c]
+            base = zeros_t()
+            for i in range(n):
+                base[ix_c(k, i)] += K[j2, i]
+            ruk = zeros_t(); ruk[ix_ru(k, j2)] = 1.0
+            add_row(f"Uub[{k},{j2}]", zc + tt, -np.inf, zeros_t(), uu[j2] - Kcn[j2] - ru0[k, j2], -(base + ruk + th_abs))
+            add_row(f"Ulb[{k},{j2}]", zc - tt, ul[j2] - Kcn[j2] + ru0[k, j2], -(base - ruk - th_abs), np.inf, zeros_t())
+    # ---- t >= |zeta| ---------------------------------------------------------------------------
+    for (j, c), zi in t_var.items():
+        zeta = np.zeros(nz); zt = zeros_t()
+        if c < n:
+            zeta[:N * m] = Gam[j][c]
+            zt[[ix_x0(cc) for cc in range(n)]] = Phi[j][c]
+        else:
+            zeta[j * m + (c - n)] = 1.0
+        e_t = np.zeros(nz); e_t[zi] = 1.0
+        add_row(f"t+[{j},{c}]", e_t - zeta, 0.0, zt, np.inf, zeros_t())      # t - zeta >= +theta part
+        add_row(f"t-[{j},{c}]", e_t + zeta, 0.0, -zt, np.inf, zeros_t())
+    # ---- loss ----------------------------------------------------------------------------------
+    P = np.zeros((nz, nz)); q0 = np.zeros(nz); Qt = np.zeros((nz, ntheta))
+    r0 = float(loss.const); r1 = loss.lin[sp].copy(); R2 = np.zeros((n, n))
+    zc, _ = z_coef(loss.lin, nz); q0 += zc
+    for w, e in terms["sq"]:
+        F = np.zeros((e.size, nz)); G = np.zeros((e.size, n))
+        for r in range(e.size):
+            F[r], G[r] = z_coef(e.C[r], nz)
+        P += 2.0 * w * F.T @ F
+        q0 += 2.0 * w * F.T @ e.d
+        Qt[:, :n] += 2.0 * w * F.T @ G
+        r0 += w * float(e.d @ e.d); r1 += 2.0 * w * G.T @ e.d; R2 += w * G.T @ G
+    for w, e in terms["ab"]:
+        for r in range(e.size):
+            if not np.any(e.C[r]):
+                r0 += w * abs(float(e.d[r]))
+    for si, (w, rows_) in enumerate(epi_specs):
+        zi = s_var0 + si
+        q0[zi] += w
+        for Crow, d in rows_:
+            zc, pc = z_coef(Crow, nz)
+            e_s = np.zeros(nz); e_s[zi] = 1.0
+            th = zeros_t(); th[:n] = pc
+            add_row(f"s+[{si}]", e_s - zc, d, th, np.inf, zeros_t())
+            add_row(f"s-[{si}]", e_s + zc, -d, -th, np.inf, zeros_t())
+    # ---- user constraints ----------------------------------------------------------------------
+    for ci, c in enumerate(cons):
+        e = c.expr
+        for r in range(e.size):
+            zc, pc = z_coef(e.C[r], nz)
+            th = zeros_t(); th[:n] = -pc
+            d = -float(e.d[r])
+            if c.kind == "<=":
+                add_row(f"user[{ci},{r}]", zc, -np.inf, zeros_t(), d, th)
+            elif c.kind == ">=":
+                add_row(f"user[{ci},{r}]", zc, d, th, np.inf, zeros_t())
+            else:
+                add_row(f"user[{ci},{r}]", zc, d, th, d, th.copy())
+
+    qp_rows = [r for r in rows if np.any(r[1])]
+    pr_rows = [r for r in rows if not np.any(r[1])]
+    nc = len(qp_rows)
+    A = np.array([r[1] for r in qp_rows]).reshape(nc, nz)
+    l0 = np.array([r[2] for r in qp_rows]); Lt = np.array([r[3] for r in qp_rows]).reshape(nc, ntheta)
+    u0 = np.array([r[4] for r in qp_rows]); Ut = np.array([r[5] for r in qp_rows]).reshape(nc, ntheta)
+    # parameter-only rows  0 in [lo, hi]  ->  pl <= Ft theta <= pu  with  value := -(theta part)
+    npr = len(pr_rows)
+    Ft = np.zeros((2 * npr, ntheta)); f0 = np.zeros(2 * npr); pl = np.full(2 * npr, -np.inf); pu = np.full(2 * npr, np.inf)
+    for i, (name, _, lo_c, lo_t, hi_c, hi_t) in enumerate(pr_rows):
+        # need lo_c + lo_t.theta <= 0 <= hi_c + hi_t.theta
+        f0[2 * i] = lo_c if np.isfinite(lo_c) else 0.0; Ft[2 * i] = lo_t; pu[2 * i] = 0.0 if np.isfinite(lo_c) else np.inf
+        f0[2 * i + 1] = hi_c if np.isfinite(hi_c) else 0.0; Ft[2 * i + 1] = hi_t; pl[2 * i + 1] = 0.0 if np.isfinite(hi_c) else -np.inf
+    keep = np.isfinite(pl) | np.isfinite(pu)
+    Ft, f0, pl, pu = Ft[keep], f0[keep], pl[keep], pu[keep]
+
+    return ParametricQP(n=n, m=m, N=N, nz=nz, nc=nc, ntheta=ntheta, P=0.5 * (P + P.T), A=A,
+                        q0=q0, Qt=Qt, l0=l0, Lt=Lt, u0=u0, Ut=Ut, f0=f0, Ft=Ft, pl=pl, pu=pu,
+                        r0=r0, r1=r1, R2=R2, Phi=Phi.reshape((N + 1) * n, n), Gam=Gam.reshape((N + 1) * n, N * m),
+                        tube=tube, row_names=[r[0] for r in qp_rows], var_names=var_names, n_v=N * m)
+
+
+# ---- host evaluation helpers (used by tests and by the literal Ze[1] export; NOT the hot path) ----
+
+def tube_reference(tube: TubeConstants, e0: np.ndarray):
+    """theta tube block for one e0 -- the arithmetic the HIP kernel ``tz_prepare`` performs."""
+    n, m, N = tube.n, tube.m, tube.N
+    pmax = tube.pmax
+    cs = [np.asarray(e0, float)]
+    betas = []
+    radx = [np.zeros(n)]; radu = [np.zeros(m)]
+    for pidx in range(pmax):
+        c = cs[-1]
+        betas.append(tube.DK @ (np.abs(c) + radx[-1]))
+        cs.append(tube.CK @ c)
+        rx = np.zeros(n); ru = np.zeros(m)
+        for l, b in enumerate(betas):
+            rx += tube.absCKpow[pidx - l] @ b
+            ru += tube.absKCKpow[pidx - l] @ b
+        radx.append(rx); radu.append(ru)
+    out = np.zeros(N * (2 * n + m))
+    for k in range(N):
+        pw = tube.power[k]
+        o = k * (2 * n + m)
+        out[o:o + n] = cs[pw]; out[o + n:o + 2 * n] = radx[pw]; out[o + 2 * n:o + 2 * n + m] = radu[pw]
+    return out
+
+
+def theta_reference(qp: ParametricQP, xbar0, e0):
+    return np.concatenate([np.asarray(xbar0, float), np.abs(np.asarray(xbar0, float)), tube_reference(qp.tube, e0)])

@@ -1,0 +1,498 @@
+// C-ABI of the MI355X TZDDPC hot path (see include/tzddpc.h).  Host side: uploads the problem,
+// packs the constraint matrix into 4x4 MFMA patches, builds the static Gram work plan, launches the
+// kernels of tz_kernels.hip.h on one HIP stream.  No torch types, no CPU compute fallback: every
+// numeric result comes out of a kernel.
+#include "tz_kernels.hip.h"
+#include "../../include/tzddpc.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+#define TZ_FAIL(code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); g_err = _b; return (code); } while (0)
+#define TZ_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
+    char _b[512]; snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    g_err = _b; return TZ_ERR_HIP; } } while (0)
+
+namespace {
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void**)&p, count * sizeof(T));
+  }
+  hipError_t upload(const T* src, size_t count) {
+    hipError_t e = alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+  }
+  hipError_t upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
+};
+
+struct DevCsr {
+  DevBuf<int> ptr, col;
+  DevBuf<double> val, c0;
+  int rows = 0;
+  hipError_t upload(const tz_affmap& m) {
+    rows = m.rows;
+    std::vector<int> p0(1, 0);
+    const int* ptr_src = m.rows ? m.ptr : p0.data();
+    hipError_t e;
+    if ((e = ptr.upload(ptr_src, (size_t)m.rows + 1)) != hipSuccess) return e;
+    int nnz = m.rows ? m.ptr[m.rows] : 0;
+    if ((e = col.upload(m.col, (size_t)nnz)) != hipSuccess) return e;
+    if ((e = val.upload(m.val, (size_t)nnz)) != hipSuccess) return e;
+    return c0.upload(m.c0, (size_t)m.rows);
+  }
+  TzCsr view() const { return TzCsr{rows, ptr.p, col.p, val.p, c0.p}; }
+};
+
+enum { K_TUBE = 0, K_IPM = 1, K_FINISH = 2, K_PLANT = 3, K_COUNT = 4 };
+
+}  // namespace
+
+struct tz_problem {
+  int device = 0;
+  int n = 0, m = 0, N = 0, nz = 0, mi = 0, ntheta = 0, npar = 0, nc_rows = 0, pmax = 0;
+  int nzp = 0, mip = 0, Tz = 0, Kc = 0, nquads = 0;
+  int max_iter = 40;
+  double tol = 1e-10, reg = 1e-12, step_frac = 0.99, cost_scale = 1.0, r0 = 0.0;
+  // constants
+  DevBuf<double> P, G, Gt, Gp, Dz, Phi, Gam, r1, R2, CK, DK, K, absCK, absKCK, par_lo, par_hi;
+  DevBuf<int> power, row_of, klist, item_ptr;
+  DevBuf<IpmItem> items;
+  DevCsr q, h, par;
+  size_t lds_bytes = 0;
+  int64_t mfma_gram = 0, mfma_chol = 0;
+  // workspace (capacity Bcap)
+  int Bcap = 0;
+  DevBuf<double> theta, tube_ws, qv, hv, x, s, lam, v, xbar, cost, in_x0, in_e0;
+  DevBuf<int> prestatus, status, iters, sticky;
+  DevBuf<uint8_t> active;
+  // closed-loop state / plant (simulate)
+  DevBuf<double> st_x, st_xbar, st_e, plantA, plantB, noise, xtraj, utraj, costtraj;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[K_COUNT];
+  size_t ev_used[K_COUNT] = {0, 0, 0, 0};
+  double t_ms[K_COUNT] = {0, 0, 0, 0};
+  int64_t t_count[K_COUNT] = {0, 0, 0, 0};
+  int lastB = 0;
+};
+
+namespace {
+
+int ensure_workspace(tz_problem* p, int B) {
+  if (B <= p->Bcap) return TZ_OK;
+  TZ_HIP(hipSetDevice(p->device));
+  size_t b = (size_t)B;
+  TZ_HIP(p->theta.alloc(b * p->ntheta));
+  TZ_HIP(p->tube_ws.alloc(b * (p->pmax + 1) * (3 * p->n + p->m)));
+  TZ_HIP(p->qv.alloc(b * p->nz));
+  TZ_HIP(p->hv.alloc(b * p->mi));
+  TZ_HIP(p->x.alloc(b * p->nz));
+  TZ_HIP(p->s.alloc(b * p->mi));
+  TZ_HIP(p->lam.alloc(b * p->mi));
+  TZ_HIP(p->v.alloc(b * p->N * p->m));
+  TZ_HIP(p->xbar.alloc(b * (p->N + 1) * p->n));
+  TZ_HIP(p->cost.alloc(b));
+  TZ_HIP(p->in_x0.alloc(b * p->n));
+  TZ_HIP(p->in_e0.alloc(b * p->n));
+  TZ_HIP(p->prestatus.alloc(b));
+  TZ_HIP(p->status.alloc(b));
+  TZ_HIP(p->iters.alloc(b));
+  TZ_HIP(p->sticky.alloc(b));
+  TZ_HIP(p->active.alloc(b * std::max(p->nc_rows, 1)));
+  TZ_HIP(p->st_x.alloc(b * p->n));
+  TZ_HIP(p->st_xbar.alloc(b * p->n));
+  TZ_HIP(p->st_e.alloc(b * p->n));
+  p->Bcap = B;
+  return TZ_OK;
+}
+
+struct Timer {
+  tz_problem* p; int k; hipEvent_t e0 = nullptr, e1 = nullptr;
+  Timer(tz_problem* p_, int k_) : p(p_), k(k_) {
+    if (!p->timing) return;
+    if (p->ev_used[k] == p->ev_pool[k].size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      p->ev_pool[k].push_back({a, b});
+    }
+    e0 = p->ev_pool[k][p->ev_used[k]].first; e1 = p->ev_pool[k][p->ev_used[k]].second;
+    p->ev_used[k]++;
+    (void)hipEventRecord(e0, p->stream);
+  }
+  ~Timer() { if (e1) (void)hipEventRecord(e1, p->stream); }
+};
+
+void drain_timing(tz_problem* p) {
+  for (int k = 0; k < K_COUNT; ++k) {
+    for (size_t i = 0; i < p->ev_used[k]; ++i) {
+      float ms = 0.f;
+      if (hipEventSynchronize(p->ev_pool[k][i].second) == hipSuccess &&
+          hipEventElapsedTime(&ms, p->ev_pool[k][i].first, p->ev_pool[k][i].second) == hipSuccess) {
+        p->t_ms[k] += ms; p->t_count[k]++;
+      }
+    }
+    p->ev_used[k] = 0;
+  }
+}
+
+// Core launch sequence on device-resident inputs: tube -> affine -> ipm -> finish.
+int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0,
+                 double* d_v, double* d_xbar, double* d_cost, int* d_status, int* d_iters, uint8_t* d_active, size_t cost_stride = 1) {
+  hipStream_t st = p->stream;
+  p->lastB = B;
+  TZ_HIP(hipMemsetAsync(p->prestatus.p, 0, (size_t)B * sizeof(int), st));
+  {
+    Timer tm(p, K_TUBE);
+    TubeParams tp{B, p->n, p->m, p->N, p->pmax, p->ntheta, p->CK.p, p->DK.p, p->absCK.p, p->absKCK.p, p->power.p,
+                  d_xbar0, d_e0, p->theta.p, p->tube_ws.p};
+    hipLaunchKernelGGL(tz_tube_kernel, dim3((B + 63) / 64), dim3(64), 0, st, tp);
+    AffineParams ap{B, p->ntheta, p->nz, p->mi, p->npar, p->q.view(), p->h.view(), p->par.view(), p->par_lo.p, p->par_hi.p,
+                    p->theta.p, p->qv.p, p->hv.p, p->prestatus.p};
+    size_t total = (size_t)B * (p->nz + p->mi + p->npar);
+    hipLaunchKernelGGL(tz_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ap);
+  }
+  {
+    Timer tm(p, K_IPM);
+    IpmParams ip{};
+    ip.B = B; ip.nz = p->nz; ip.mi = p->mi; ip.nzp = p->nzp; ip.mip = p->mip; ip.Tz = p->Tz; ip.Kc = p->Kc; ip.nquads = p->nquads;
+    ip.P = p->P.p; ip.G = p->G.p; ip.Gt = p->Gt.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p;
+    ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
+    ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
+    ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac;
+    hipLaunchKernelGGL(tz_ipm_kernel, dim3(B), dim3(TZ_THREADS), p->lds_bytes, st, ip);
+  }
+  {
+    Timer tm(p, K_FINISH);
+    FinishParams fp{B, p->n, p->m, p->N, p->nz, p->mi, p->nzp, p->nc_rows, p->P.p, p->Dz.p, p->Phi.p, p->Gam.p,
+                    p->r1.p, p->R2.p, p->r0, p->cost_scale, p->row_of.p, d_xbar0, p->qv.p, p->x.p, p->s.p, p->lam.p,
+                    d_status, d_v, d_xbar, d_cost, d_active, cost_stride};
+    hipLaunchKernelGGL(tz_finish_kernel, dim3(B), dim3(64), 0, st, fp);
+  }
+  TZ_HIP(hipGetLastError());
+  return TZ_OK;
+}
+
+int launch_plant(tz_problem* p, int B, const double* d_A, const double* d_Bm, const double* d_w, size_t w_stride,
+                 const double* d_v, const double* d_xbar_pred, const int* d_status,
+                 double* d_x, double* d_xbar, double* d_e, double* d_u, size_t u_stride, double* d_xout, size_t x_stride, int* d_sticky) {
+  Timer tm(p, K_PLANT);
+  PlantParams pp{B, p->n, p->m, p->N, p->K.p, d_A, d_Bm, d_v, d_xbar_pred, d_w, w_stride, d_status, d_x, d_xbar, d_e,
+                 d_u, u_stride, d_xout, x_stride, d_sticky};
+  hipLaunchKernelGGL(tz_plant_kernel, dim3((B + 63) / 64), dim3(64), 0, p->stream, pp);
+  TZ_HIP(hipGetLastError());
+  return TZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tz_abi_version(void) { return TZ_ABI_VERSION; }
+const char* tz_last_error(void) { return g_err.c_str(); }
+
+int tz_device_count(int* count) {
+  if (!count) TZ_FAIL(TZ_ERR_INVALID, "count is null");
+  TZ_HIP(hipGetDeviceCount(count));
+  return TZ_OK;
+}
+
+int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
+  if (!d || !out) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  if (d->abi_version != TZ_ABI_VERSION) TZ_FAIL(TZ_ERR_INVALID, "abi_version %d != %d", d->abi_version, TZ_ABI_VERSION);
+  if (d->n < 1 || d->n > TZ_NMAX || d->m < 1 || d->m > TZ_MMAX) TZ_FAIL(TZ_ERR_UNSUPPORTED, "dim_x must be 1..%d and dim_u 1..%d", TZ_NMAX, TZ_MMAX);
+  if (d->N < 1 || d->nz < d->N * d->m || d->mi < 1) TZ_FAIL(TZ_ERR_INVALID, "inconsistent sizes N=%d nz=%d mi=%d", d->N, d->nz, d->mi);
+  if (d->nz > 256) TZ_FAIL(TZ_ERR_UNSUPPORTED, "nz=%d > 256 decision variables not supported by tz_ipm_kernel", d->nz);
+  if (d->ntheta != 2 * d->n + d->N * (2 * d->n + d->m)) TZ_FAIL(TZ_ERR_INVALID, "ntheta mismatch");
+  if (d->q.rows != d->nz || d->h.rows != d->mi) TZ_FAIL(TZ_ERR_INVALID, "affine map row counts do not match nz / mi");
+  for (int k = 0; k < d->N; ++k)
+    if (d->power[k] < 0 || d->power[k] > d->pmax) TZ_FAIL(TZ_ERR_INVALID, "power[%d]=%d outside 0..pmax", k, d->power[k]);
+  for (int r = 0; r < d->mi; ++r)
+    if (d->row_of[r] < 0 || d->row_of[r] >= std::max(d->nc_rows, 1)) TZ_FAIL(TZ_ERR_INVALID, "row_of[%d] out of range", r);
+  int ndev = 0;
+  TZ_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) TZ_FAIL(TZ_ERR_HIP, "no HIP device visible: the TZDDPC hot path has no CPU fallback");
+  if (device < 0 || device >= ndev) TZ_FAIL(TZ_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+  TZ_HIP(hipSetDevice(device));
+
+  tz_problem* p = new tz_problem();
+  std::unique_ptr<tz_problem> guard(p);
+  p->device = device;
+  p->n = d->n; p->m = d->m; p->N = d->N; p->nz = d->nz; p->mi = d->mi; p->ntheta = d->ntheta;
+  p->npar = d->par.rows; p->nc_rows = d->nc_rows; p->pmax = d->pmax;
+  p->max_iter = d->max_iter > 0 ? d->max_iter : 40;
+  p->tol = d->tol > 0 ? d->tol : 1e-10; p->reg = d->reg > 0 ? d->reg : 1e-12;
+  p->step_frac = (d->step_frac > 0 && d->step_frac < 1) ? d->step_frac : 0.99;
+  p->cost_scale = d->cost_scale; p->r0 = d->r0;
+  const int nz = d->nz, mi = d->mi;
+  p->Tz = (nz + 3) / 4; p->nzp = 4 * p->Tz;
+  p->Kc = (mi + 3) / 4; p->mip = 4 * p->Kc;
+  const int Tz = p->Tz, Kc = p->Kc, nzp = p->nzp, mip = p->mip;
+  p->nquads = 0;
+  for (int I = 0; I < Tz; ++I) p->nquads += (I >> 2) + 1;
+
+  // padded dense copies
+  std::vector<double> P((size_t)nzp * nzp, 0.0), G((size_t)mip * nzp, 0.0), Gt((size_t)nzp * mip, 0.0), Gp((size_t)Kc * Tz * 16, 0.0);
+  for (int r = 0; r < nz; ++r) for (int c = 0; c < nz; ++c) P[(size_t)r * nzp + c] = d->P[(size_t)r * nz + c];
+  for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) {
+    double v = d->G[(size_t)r * nz + c];
+    G[(size_t)r * nzp + c] = v; Gt[(size_t)c * mip + r] = v;
+    Gp[((size_t)(r >> 2) * Tz + (c >> 2)) * 16 + 4 * (r & 3) + (c & 3)] = v;
+  }
+  // Gram plan: item = (block of 4 tile rows I0..I0+3, quads q0..q0+nq-1), k-list = chunks where the 16 columns are non-zero
+  std::vector<int> klist;
+  std::vector<IpmItem> items;
+  std::vector<double> cost;
+  const int NB = (Tz + 3) / 4;
+  for (int IB = 0; IB < NB; ++IB) {
+    const int kptr = (int)klist.size();
+    for (int kc = 0; kc < Kc; ++kc) {
+      bool nzr = false;
+      for (int r = 4 * kc; r < std::min(4 * kc + 4, mi) && !nzr; ++r)
+        for (int c = 16 * IB; c < std::min(16 * IB + 16, nz); ++c)
+          if (G[(size_t)r * nzp + c] != 0.0) { nzr = true; break; }
+      if (nzr) klist.push_back(kc);
+    }
+    const int klen = (int)klist.size() - kptr;
+    const int Ilast = std::min(4 * IB + 3, Tz - 1);
+    const int qmax = Ilast >> 2;          // quads 0..qmax exist for the last row of the block
+    for (int q0 = 0; q0 <= qmax; q0 += 2) {
+      IpmItem it{4 * IB, q0, std::min(2, qmax - q0 + 1), kptr, klen};
+      items.push_back(it);
+      cost.push_back((double)klen * 4 * it.nq + 8);
+    }
+  }
+  // LPT assignment to the 4 waves
+  std::vector<int> order(items.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  std::vector<std::vector<int>> per_wave(TZ_NWAVES);
+  double load[TZ_NWAVES] = {0, 0, 0, 0};
+  for (int idx : order) {
+    int w = (int)(std::min_element(load, load + TZ_NWAVES) - load);
+    per_wave[w].push_back(idx); load[w] += cost[idx];
+  }
+  std::vector<IpmItem> items_sorted;
+  std::vector<int> item_ptr(TZ_NWAVES + 1, 0);
+  p->mfma_gram = 0;
+  for (int w = 0; w < TZ_NWAVES; ++w) {
+    for (int idx : per_wave[w]) { items_sorted.push_back(items[idx]); p->mfma_gram += (int64_t)items[idx].klen * 8; }
+    item_ptr[w + 1] = (int)items_sorted.size();
+  }
+  p->mfma_chol = 0;
+  for (int pp = 0; pp < Tz; ++pp)
+    for (int I = pp + 1; I < Tz; ++I) p->mfma_chol += (I >> 2) - ((pp + 1) >> 2) + 1;
+
+  TZ_HIP(p->P.upload(P)); TZ_HIP(p->G.upload(G)); TZ_HIP(p->Gt.upload(Gt)); TZ_HIP(p->Gp.upload(Gp));
+  if (klist.empty()) klist.push_back(0);
+  TZ_HIP(p->klist.upload(klist)); TZ_HIP(p->items.upload(items_sorted)); TZ_HIP(p->item_ptr.upload(item_ptr));
+  TZ_HIP(p->q.upload(d->q)); TZ_HIP(p->h.upload(d->h)); TZ_HIP(p->par.upload(d->par));
+  TZ_HIP(p->par_lo.upload(d->par_lo, (size_t)p->npar)); TZ_HIP(p->par_hi.upload(d->par_hi, (size_t)p->npar));
+  TZ_HIP(p->Dz.upload(d->Dz, (size_t)nz));
+  TZ_HIP(p->Phi.upload(d->Phi, (size_t)(d->N + 1) * d->n * d->n));
+  TZ_HIP(p->Gam.upload(d->Gam, (size_t)(d->N + 1) * d->n * d->N * d->m));
+  TZ_HIP(p->r1.upload(d->r1, (size_t)d->n)); TZ_HIP(p->R2.upload(d->R2, (size_t)d->n * d->n));
+  TZ_HIP(p->CK.upload(d->CK, (size_t)d->n * d->n)); TZ_HIP(p->DK.upload(d->DK, (size_t)d->n * d->n));
+  TZ_HIP(p->K.upload(d->K, (size_t)d->m * d->n));
+  TZ_HIP(p->absCK.upload(d->absCKpow, (size_t)std::max(d->pmax, 1) * d->n * d->n));
+  TZ_HIP(p->absKCK.upload(d->absKCKpow, (size_t)std::max(d->pmax, 1) * d->m * d->n));
+  TZ_HIP(p->power.upload(d->power, (size_t)d->N));
+  TZ_HIP(p->row_of.upload(d->row_of, (size_t)mi));
+
+  const size_t doubles = (size_t)p->nquads * 64 + (size_t)Tz * 16 + 10 * (size_t)nzp + 10 * (size_t)mip + 16 + 2;
+  p->lds_bytes = doubles * sizeof(double);
+  hipDeviceProp_t prop;
+  TZ_HIP(hipGetDeviceProperties(&prop, device));
+  if (p->lds_bytes > (size_t)prop.sharedMemPerBlock && p->lds_bytes > 160 * 1024)
+    TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
+  TZ_HIP(hipFuncSetAttribute((const void*)tz_ipm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+  TZ_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  p->own_stream = true;
+  *out = guard.release();
+  return TZ_OK;
+}
+
+int tz_problem_destroy(tz_problem* p) {
+  if (!p) return TZ_OK;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  for (int k = 0; k < K_COUNT; ++k)
+    for (auto& e : p->ev_pool[k]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return TZ_OK;
+}
+
+int tz_problem_set_stream(tz_problem* p, void* stream) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  TZ_HIP(hipSetDevice(p->device));
+  if (p->stream) TZ_HIP(hipStreamSynchronize(p->stream));
+  if (p->own_stream && p->stream) { TZ_HIP(hipStreamDestroy(p->stream)); p->own_stream = false; }
+  if (stream == nullptr) { TZ_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)); p->own_stream = true; }
+  else p->stream = (hipStream_t)stream;
+  return TZ_OK;
+}
+
+int tz_problem_sync(tz_problem* p) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  TZ_HIP(hipSetDevice(p->device));
+  TZ_HIP(hipStreamSynchronize(p->stream));
+  return TZ_OK;
+}
+
+int tz_solve_batch(tz_problem* p, int32_t B, const double* xbar0, const double* e0, double* v, double* xbar,
+                   double* cost, int32_t* status, int32_t* iters, uint8_t* active, int mem) {
+  if (!p || !xbar0 || !e0 || !v || !xbar || !cost || !status) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  if (B < 0) TZ_FAIL(TZ_ERR_INVALID, "negative batch size");
+  if (B == 0) return TZ_OK;
+  TZ_HIP(hipSetDevice(p->device));
+  int rc = ensure_workspace(p, B);
+  if (rc) return rc;
+  const size_t bn = (size_t)B * p->n * sizeof(double);
+  if (mem == TZ_MEM_DEVICE) {
+    return launch_solve(p, B, xbar0, e0, v, xbar, cost, status, iters, active);
+  }
+  if (mem != TZ_MEM_HOST) TZ_FAIL(TZ_ERR_INVALID, "mem must be TZ_MEM_HOST or TZ_MEM_DEVICE");
+  hipStream_t st = p->stream;
+  TZ_HIP(hipMemcpyAsync(p->in_x0.p, xbar0, bn, hipMemcpyHostToDevice, st));
+  TZ_HIP(hipMemcpyAsync(p->in_e0.p, e0, bn, hipMemcpyHostToDevice, st));
+  rc = launch_solve(p, B, p->in_x0.p, p->in_e0.p, p->v.p, p->xbar.p, p->cost.p, p->status.p, p->iters.p, active ? p->active.p : nullptr);
+  if (rc) return rc;
+  TZ_HIP(hipMemcpyAsync(v, p->v.p, (size_t)B * p->N * p->m * sizeof(double), hipMemcpyDeviceToHost, st));
+  TZ_HIP(hipMemcpyAsync(xbar, p->xbar.p, (size_t)B * (p->N + 1) * p->n * sizeof(double), hipMemcpyDeviceToHost, st));
+  TZ_HIP(hipMemcpyAsync(cost, p->cost.p, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+  TZ_HIP(hipMemcpyAsync(status, p->status.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (iters) TZ_HIP(hipMemcpyAsync(iters, p->iters.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (active) TZ_HIP(hipMemcpyAsync(active, p->active.p, (size_t)B * p->nc_rows, hipMemcpyDeviceToHost, st));
+  TZ_HIP(hipStreamSynchronize(st));
+  return TZ_OK;
+}
+
+int tz_mpc_step(tz_problem* p, int32_t B, double* x, double* xbar, double* e, const double* w,
+                const double* A_true, const double* B_true, double* u_out, double* cost, int32_t* status) {
+  if (!p || !x || !xbar || !e || !w || !A_true || !B_true || !cost || !status) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  if (B <= 0) TZ_FAIL(TZ_ERR_INVALID, "batch size must be positive");
+  TZ_HIP(hipSetDevice(p->device));
+  int rc = ensure_workspace(p, B);
+  if (rc) return rc;
+  rc = launch_solve(p, B, xbar, e, p->v.p, p->xbar.p, cost, status, p->iters.p, nullptr);
+  if (rc) return rc;
+  return launch_plant(p, B, A_true, B_true, w, (size_t)p->n, p->v.p, p->xbar.p, status, x, xbar, e,
+                      u_out, (size_t)p->m, nullptr, 0, nullptr);
+}
+
+int tz_simulate_batch(tz_problem* p, int32_t B, int32_t T, const double* x0, const double* noise,
+                      const double* A_true, const double* B_true, double* x_traj, double* u_traj,
+                      double* cost, int32_t* status, int mem) {
+  if (!p || !x0 || !noise || !A_true || !B_true || !x_traj || !u_traj || !status) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  if (B <= 0 || T <= 0) TZ_FAIL(TZ_ERR_INVALID, "B and T must be positive");
+  TZ_HIP(hipSetDevice(p->device));
+  int rc = ensure_workspace(p, B);
+  if (rc) return rc;
+  hipStream_t st = p->stream;
+  const int n = p->n, m = p->m;
+  const bool host = (mem == TZ_MEM_HOST);
+  if (!host && mem != TZ_MEM_DEVICE) TZ_FAIL(TZ_ERR_INVALID, "mem must be TZ_MEM_HOST or TZ_MEM_DEVICE");
+  const double *dA = A_true, *dB = B_true, *dnoise = noise;
+  double *dx = x_traj, *du = u_traj, *dcost = cost;
+  if (host) {
+    TZ_HIP(p->plantA.upload(A_true, (size_t)n * n)); TZ_HIP(p->plantB.upload(B_true, (size_t)n * m));
+    TZ_HIP(p->noise.upload(noise, (size_t)B * T * n));
+    TZ_HIP(p->xtraj.alloc((size_t)B * (T + 1) * n)); TZ_HIP(p->utraj.alloc((size_t)B * T * m));
+    TZ_HIP(p->costtraj.alloc((size_t)B * T));
+    dA = p->plantA.p; dB = p->plantB.p; dnoise = p->noise.p; dx = p->xtraj.p; du = p->utraj.p; dcost = p->costtraj.p;
+    TZ_HIP(hipMemcpy2DAsync(dx, (size_t)(T + 1) * n * sizeof(double), x0, (size_t)n * sizeof(double), (size_t)n * sizeof(double), B, hipMemcpyHostToDevice, st));
+    TZ_HIP(hipMemcpyAsync(p->st_x.p, x0, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, st));
+  } else {
+    if (!cost) { TZ_HIP(p->costtraj.alloc((size_t)B * T)); dcost = p->costtraj.p; }
+    TZ_HIP(hipMemcpy2DAsync(dx, (size_t)(T + 1) * n * sizeof(double), x0, (size_t)n * sizeof(double), (size_t)n * sizeof(double), B, hipMemcpyDeviceToDevice, st));
+    TZ_HIP(hipMemcpyAsync(p->st_x.p, x0, (size_t)B * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  TZ_HIP(hipMemcpyAsync(p->st_xbar.p, p->st_x.p, (size_t)B * n * sizeof(double), hipMemcpyDeviceToDevice, st));   // xbar = x0 (:69)
+  TZ_HIP(hipMemsetAsync(p->st_e.p, 0, (size_t)B * n * sizeof(double), st));                                        // e = 0   (:70)
+  TZ_HIP(hipMemsetAsync(p->sticky.p, 0, (size_t)B * sizeof(int), st));
+  for (int t = 0; t < T; ++t) {
+    rc = launch_solve(p, B, p->st_xbar.p, p->st_e.p, p->v.p, p->xbar.p, dcost + t, p->status.p, p->iters.p, nullptr, (size_t)T);
+    if (rc) return rc;
+    rc = launch_plant(p, B, dA, dB, dnoise + (size_t)t * n, (size_t)T * n, p->v.p, p->xbar.p, p->status.p,
+                      p->st_x.p, p->st_xbar.p, p->st_e.p, du + (size_t)t * m, (size_t)T * m,
+                      dx + (size_t)(t + 1) * n, (size_t)(T + 1) * n, p->sticky.p);
+    if (rc) return rc;
+  }
+  if (host) {
+    TZ_HIP(hipMemcpyAsync(x_traj, dx, (size_t)B * (T + 1) * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    TZ_HIP(hipMemcpyAsync(u_traj, du, (size_t)B * T * m * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (cost) TZ_HIP(hipMemcpyAsync(cost, dcost, (size_t)B * T * sizeof(double), hipMemcpyDeviceToHost, st));
+    TZ_HIP(hipMemcpyAsync(status, p->sticky.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    TZ_HIP(hipStreamSynchronize(st));
+  } else {
+    TZ_HIP(hipMemcpyAsync(status, p->sticky.p, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, st));
+  }
+  return TZ_OK;
+}
+
+int tz_timing_enable(tz_problem* p, int enable) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  TZ_HIP(hipSetDevice(p->device));
+  if (p->timing) drain_timing(p);
+  p->timing = enable != 0;
+  for (int k = 0; k < K_COUNT; ++k) { p->t_ms[k] = 0; p->t_count[k] = 0; }
+  return TZ_OK;
+}
+
+int tz_timing_get(tz_problem* p, int kernel, double* total_ms, int64_t* launches) {
+  if (!p || kernel < 0 || kernel >= K_COUNT || !total_ms || !launches) TZ_FAIL(TZ_ERR_INVALID, "bad argument");
+  TZ_HIP(hipSetDevice(p->device));
+  drain_timing(p);
+  *total_ms = p->t_ms[kernel]; *launches = p->t_count[kernel];
+  return TZ_OK;
+}
+
+int tz_ipm_plan_info(tz_problem* p, int64_t* mfma_gram_per_iter, int64_t* mfma_chol_per_iter, int64_t* lds_bytes, int64_t* patch_bytes) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  if (mfma_gram_per_iter) *mfma_gram_per_iter = p->mfma_gram;
+  if (mfma_chol_per_iter) *mfma_chol_per_iter = p->mfma_chol;
+  if (lds_bytes) *lds_bytes = (int64_t)p->lds_bytes;
+  if (patch_bytes) *patch_bytes = (int64_t)p->Gp.n * 8;
+  return TZ_OK;
+}
+
+int tz_debug_fetch(tz_problem* p, int32_t b, int what, double* out, int32_t capacity) {
+  if (!p || !out) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  if (b < 0 || b >= p->lastB) TZ_FAIL(TZ_ERR_INVALID, "trajectory %d outside the last batch (%d)", b, p->lastB);
+  TZ_HIP(hipSetDevice(p->device));
+  TZ_HIP(hipStreamSynchronize(p->stream));
+  const double* src = nullptr; int len = 0;
+  switch (what) {
+    case 0: src = p->theta.p + (size_t)b * p->ntheta; len = p->ntheta; break;
+    case 1: src = p->qv.p + (size_t)b * p->nz; len = p->nz; break;
+    case 2: src = p->hv.p + (size_t)b * p->mi; len = p->mi; break;
+    case 3: src = p->x.p + (size_t)b * p->nz; len = p->nz; break;
+    case 4: src = p->s.p + (size_t)b * p->mi; len = p->mi; break;
+    case 5: src = p->lam.p + (size_t)b * p->mi; len = p->mi; break;
+    default: TZ_FAIL(TZ_ERR_INVALID, "unknown debug item %d", what);
+  }
+  if (capacity < len) TZ_FAIL(TZ_ERR_INVALID, "capacity %d < %d", capacity, len);
+  TZ_HIP(hipMemcpy(out, src, (size_t)len * sizeof(double), hipMemcpyDeviceToHost));
+  return len;
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+"""ctypes binding of ``libtzddpc_hip.so`` (C-ABI in ``include/tzddpc.h``).
+
+Thin by design: sizes and pointers go in, nothing is computed here.  There is no CPU fallback --
+if the shared library is missing or no HIP device is visible the calls raise ``NativeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+TZ_ABI_VERSION = 1
+TZ_MEM_HOST, TZ_MEM_DEVICE = 0, 1
+TZ_SOLVED, TZ_MAX_ITER, TZ_NUMERICAL, TZ_INFEASIBLE = 0, 1, 2, 3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtzddpc_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class AffMap(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("ptr", _ip), ("col", _ip), ("val", _dp), ("c0", _dp)]
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("N", C.c_int32),
+        ("nz", C.c_int32), ("mi", C.c_int32), ("ntheta", C.c_int32),
+        ("P", _dp), ("G", _dp), ("q", AffMap), ("h", AffMap), ("par", AffMap),
+        ("par_lo", _dp), ("par_hi", _dp),
+        ("cost_scale", C.c_double), ("r0", C.c_double), ("r1", _dp), ("R2", _dp),
+        ("Dz", _dp), ("Phi", _dp), ("Gam", _dp),
+        ("nc_rows", C.c_int32), ("row_of", _ip),
+        ("CK", _dp), ("DK", _dp), ("K", _dp), ("pmax", C.c_int32), ("absCKpow", _dp), ("absKCKpow", _dp), ("power", _ip),
+        ("max_iter", C.c_int32), ("tol", C.c_double), ("reg", C.c_double), ("step_frac", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def build_hint() -> str:
+    return ("build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950 -shared -fPIC tzddpc_amd/csrc/tzddpc_hip.hip)")
+
+
+def lib():
+    """Load the shared library once; declare every symbol of include/tzddpc.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(f"{LIB_PATH} not found: the TZDDPC hot path runs only as HIP kernels; {build_hint()}")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
+    vp = C.c_void_p
+    L.tz_abi_version.restype = C.c_int
+    L.tz_last_error.restype = C.c_char_p
+    L.tz_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.tz_problem_create.argtypes = [C.c_int, C.POINTER(ProblemDesc), C.POINTER(vp)]
+    L.tz_problem_destroy.argtypes = [vp]
+    L.tz_problem_set_stream.argtypes = [vp, vp]
+    L.tz_problem_sync.argtypes = [vp]
+    L.tz_solve_batch.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.tz_simulate_batch.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.tz_mpc_step.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.tz_timing_enable.argtypes = [vp, C.c_int]
+    L.tz_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.tz_ipm_plan_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.tz_debug_fetch.argtypes = [vp, C.c_int32, C.c_int, vp, C.c_int32]
+    for name in ("tz_device_count", "tz_problem_create", "tz_problem_destroy", "tz_problem_set_stream", "tz_problem_sync",
+                 "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_timing_enable", "tz_timing_get",
+                 "tz_ipm_plan_info", "tz_debug_fetch"):
+        getattr(L, name).restype = C.c_int
+    if L.tz_abi_version() != TZ_ABI_VERSION:
+        raise NativeError(f"ABI mismatch: library {L.tz_abi_version()} vs binding {TZ_ABI_VERSION}")
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy",
+                    "tz_problem_set_stream", "tz_problem_sync", "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step",
+                    "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_debug_fetch")
+
+
+def check(rc: int, what: str):
+    if rc < 0:
+        raise NativeError(f"{what} failed ({rc}): {lib().tz_last_error().decode(errors='replace')}")
+    return rc
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib().tz_device_count(C.byref(n)), "tz_device_count")
+    return n.value
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a, typ):
+    return a.ctypes.data_as(typ)
+
+
+def _csr(M: np.ndarray, c0: np.ndarray, keep: list):
+    """dense (rows x ntheta) -> AffMap; `keep` pins the numpy buffers for the lifetime of the desc."""
+    M = np.atleast_2d(_f64(M))
+    rows = M.shape[0] if M.size else len(c0)
+    ptr = np.zeros(rows + 1, dtype=np.int32)
+    cols, vals = [], []
+    for r in range(rows):
+        nzc = np.nonzero(M[r])[0] if M.size else np.zeros(0, dtype=int)
+        cols.append(nzc); vals.append(M[r, nzc] if M.size else np.zeros(0))
+        ptr[r + 1] = ptr[r] + len(nzc)
+    col = _i32(np.concatenate(cols) if cols else np.zeros(0))
+    val = _f64(np.concatenate(vals) if vals else np.zeros(0))
+    if col.size == 0:
+        col = np.zeros(1, dtype=np.int32); val = np.zeros(1)
+    c0 = _f64(c0) if len(c0) else np.zeros(1)
+    keep += [ptr, col, val, c0]
+    return AffMap(rows, _ptr(ptr, _ip), _ptr(col, _ip), _ptr(val, _dp), _ptr(c0, _dp))
+
+
+class Problem:
+    """Owner of one ``tz_problem`` handle."""
+
+    def __init__(self, device: int, *, n, m, N, P, G, q0, Qt, h0, Ht, par0, Part, par_lo, par_hi, cost_scale, r0, r1, R2,
+                 Dz, Phi, Gam, nc_rows, row_of, CK, DK, K, pmax, absCKpow, absKCKpow, power,
+                 max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99):
+        L = lib()
+        keep = []
+        d = ProblemDesc()
+        d.abi_version = TZ_ABI_VERSION
+        d.n, d.m, d.N = int(n), int(m), int(N)
+        P = _f64(P); G = _f64(G)
+        d.nz, d.mi = P.shape[0], G.shape[0]
+        d.ntheta = 2 * n + N * (2 * n + m)
+        arrs = dict(P=P, G=G, r1=_f64(r1), R2=_f64(R2), Dz=_f64(Dz), Phi=_f64(Phi), Gam=_f64(Gam), CK=_f64(CK), DK=_f64(DK),
+                    K=_f64(K), absCKpow=_f64(absCKpow), absKCKpow=_f64(absKCKpow))
+        for k, a in arrs.items():
+            setattr(d, k, _ptr(a, _dp)); keep.append(a)
+        d.q = _csr(Qt, q0, keep); d.h = _csr(Ht, h0, keep); d.par = _csr(Part, par0, keep)
+        plo = _f64(par_lo) if len(par_lo) else np.zeros(1); phi = _f64(par_hi) if len(par_hi) else np.zeros(1)
+        keep += [plo, phi]
+        d.par_lo = _ptr(plo, _dp); d.par_hi = _ptr(phi, _dp)
+        d.cost_scale = float(cost_scale); d.r0 = float(r0)
+        ro = _i32(row_of); pw = _i32(power); keep += [ro, pw]
+        d.nc_rows = int(nc_rows); d.row_of = _ptr(ro, _ip)
+        d.pmax = int(pmax); d.power = _ptr(pw, _ip)
+        d.max_iter = int(max_iter); d.tol = float(tol); d.reg = float(reg); d.step_frac = float(step_frac)
+        self.n, self.m, self.N, self.nz, self.mi, self.nc_rows, self.ntheta = int(n), int(m), int(N), d.nz, d.mi, int(nc_rows), d.ntheta
+        h = C.c_void_p()
+        check(L.tz_problem_create(int(device), C.byref(d), C.byref(h)), "tz_problem_create")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tz_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-pointer entry points -------------------------------------------------------------
+    def solve_batch(self, xbar0: np.ndarray, e0: np.ndarray, want_active: bool = False):
+        xbar0 = _f64(xbar0).reshape(-1, self.n); e0 = _f64(e0).reshape(-1, self.n)
+        B = xbar0.shape[0]
+        if e0.shape[0] != B:
+            raise ValueError("xbar0 and e0 must have the same batch size")
+        v = np.empty((B, self.N, self.m)); xbar = np.empty((B, self.N + 1, self.n)); cost = np.empty(B)
+        status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32)
+        active = np.zeros((B, self.nc_rows), dtype=np.uint8) if want_active else None
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        check(lib().tz_solve_batch(self._h, B, vp(xbar0), vp(e0), vp(v), vp(xbar), vp(cost), vp(status), vp(iters), vp(active),
+                                   TZ_MEM_HOST), "tz_solve_batch")
+        return v, xbar, cost, status, iters, active
+
+    def simulate_batch(self, x0, noise, A_true, B_true):
+        x0 = _f64(x0).reshape(-1, self.n); B = x0.shape[0]
+        noise = _f64(noise).reshape(B, -1, self.n); T = noise.shape[1]
+        A_true = _f64(A_true); B_true = _f64(B_true).reshape(self.n, self.m)
+        xt = np.empty((B, T + 1, self.n)); ut = np.empty((B, T, self.m)); cost = np.empty((B, T)); status = np.empty(B, dtype=np.int32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(lib().tz_simulate_batch(self._h, B, T, vp(x0), vp(noise), vp(A_true), vp(B_true), vp(xt), vp(ut), vp(cost), vp(status),
+                                      TZ_MEM_HOST), "tz_simulate_batch")
+        return xt, ut, cost, status
+
+    # ---- device-pointer entry points (torch tensors: pass .data_ptr()) --------------------------
+    def solve_batch_ptr(self, B, xbar0, e0, v, xbar, cost, status, iters=None, active=None):
+        check(lib().tz_solve_batch(self._h, int(B), xbar0, e0, v, xbar, cost, status, iters, active, TZ_MEM_DEVICE), "tz_solve_batch")
+
+    def mpc_step_ptr(self, B, x, xbar, e, w, A_true, B_true, u_out, cost, status):
+        check(lib().tz_mpc_step(self._h, int(B), x, xbar, e, w, A_true, B_true, u_out, cost, status), "tz_mpc_step")
+
+    def simulate_batch_ptr(self, B, T, x0, noise, A_true, B_true, x_traj, u_traj, cost, status):
+        check(lib().tz_simulate_batch(self._h, int(B), int(T), x0, noise, A_true, B_true, x_traj, u_traj, cost, status,
+                                      TZ_MEM_DEVICE), "tz_simulate_batch")
+
+    def set_stream(self, stream_ptr: Optional[int]):
+        check(lib().tz_problem_set_stream(self._h, stream_ptr), "tz_problem_set_stream")
+
+    def sync(self):
+        check(lib().tz_problem_sync(self._h), "tz_problem_sync")
+
+    def timing_enable(self, on: bool = True):
+        check(lib().tz_timing_enable(self._h, int(on)), "tz_timing_enable")
+
+    def timing_get(self, kernel: int):
+        ms = C.c_double(0); cnt = C.c_int64(0)
+        check(lib().tz_timing_get(self._h, kernel, C.byref(ms), C.byref(cnt)), "tz_timing_get")
+        return ms.value, cnt.value
+
+    def plan_info(self):
+        a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().tz_ipm_plan_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "tz_ipm_plan_info")
+        return dict(mfma_gram_per_iter=a.value, mfma_chol_per_iter=b.value, lds_bytes=c.value, patch_bytes=d.value)
+
+    def debug_fetch(self, b: int, what: int) -> np.ndarray:
+        cap = max(self.nz, self.mi, self.ntheta)
+        out = np.empty(cap)
+        n = check(lib().tz_debug_fetch(self._h, int(b), int(what), out.ctypes.data_as(C.c_void_p), cap), "tz_debug_fetch")
+        return out[:n].copy()

@@ -1,0 +1,260 @@
+"""``TZDDPC`` -- API-compatible front end of the MI355X hot path.
+
+Same class / method surface as the reference (``tzddpc/tzddpc.py:11-377``):
+
+    TZDDPC(data) . build_zonotopes_theta(zonotopes) . build_problem(N, loss_cb, constr_cb)
+                 . build_problem_simplified(k0, N, loss_cb, constr_cb) . solve(xbar0, e0, **kw)
+
+plus the batched entry points the GPU path exists for: ``solve_batch`` and ``simulate_batch``.
+Host code here only *assembles* (numpy, build time).  Every per-step number -- tube propagation,
+parameter application, the QP solve, trajectory recovery, the plant update -- is produced by HIP
+kernels behind the C-ABI (``include/tzddpc.h``); without the library or a GPU the calls raise.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+from . import native
+from .builder import ParametricQP, StructureError, build_parametric_qp
+from .gain import compute_theta as _compute_theta
+from .objects import Data, DataDrivenDataset, SystemZonotopes, Theta
+from .zonotope import MatrixZonotope, Zonotope, compute_LTI_matrix_zonotope, concatenate_zonotope
+
+
+class _Value:
+    def __init__(self, value):
+        self.value = value
+
+
+class TubeZonotope:
+    """What ``solve`` returns in 4th position: the reference hands back the CVXZonotope ``Ze[1]``
+    whose ``.Z.value`` is ``[center | generators]`` (``tzddpc/tzddpc.py:377``,
+    ``examples/1.double_integrator_sim.py:89-90``)."""
+
+    def __init__(self, Z: np.ndarray):
+        self.Z = _Value(Z)
+
+    @property
+    def center(self):
+        return self.Z.value[:, 0]
+
+    @property
+    def generators(self):
+        return self.Z.value[:, 1:]
+
+    @property
+    def num_generators(self):
+        return self.Z.value.shape[1] - 1
+
+
+def _ruiz(P, G, q_ref, iters=15):
+    """Ruiz equilibration of [[P, G'], [G, 0]] + cost normalisation (host, build time)."""
+    nz, mi = P.shape[0], G.shape[0]
+    D = np.ones(nz); E = np.ones(mi)
+    Ps = P.copy(); Gs = G.copy()
+    for _ in range(iters):
+        cn = np.maximum(np.abs(Ps).max(axis=0, initial=0.0), np.abs(Gs).max(axis=0, initial=0.0))
+        rn = np.abs(Gs).max(axis=1, initial=0.0)
+        d = 1.0 / np.sqrt(np.where(cn < 1e-8, 1.0, cn)); e = 1.0 / np.sqrt(np.where(rn < 1e-8, 1.0, rn))
+        Ps = d[:, None] * Ps * d[None, :]; Gs = e[:, None] * Gs * d[None, :]
+        D *= d; E *= e
+    c = 1.0 / max(np.abs(Ps).max(initial=0.0), np.abs(D * q_ref).max(initial=0.0), 1e-300)
+    return D, E, c
+
+
+class TZDDPC(object):
+    optimization_problem = None
+    dataset: DataDrivenDataset
+    zonotopes: SystemZonotopes
+    Mdata: MatrixZonotope
+    Mdelta: MatrixZonotope
+    MdataK: MatrixZonotope
+    theta: Theta
+
+    def __init__(self, data: Data, device: int = 0):
+        """:param data: input/state data, each T x features (reference ``tzddpc/tzddpc.py:20-28``)."""
+        self.device = device
+        self._native: Optional[native.Problem] = None
+        self.qp: Optional[ParametricQP] = None
+        self.update_identification_data(data)
+
+    # ---- reference :30-43 ------------------------------------------------------------------------
+    @property
+    def num_samples(self) -> int:
+        return self.dataset.Um.shape[0] + 1
+
+    @property
+    def dim_u(self) -> int:
+        return self.dataset.Um.shape[1]
+
+    @property
+    def dim_x(self) -> int:
+        return self.dataset.Xp.shape[1]
+
+    def update_identification_data(self, data: Data):
+        """Reference ``:45-65``; the problem must be rebuilt afterwards."""
+        u = np.asarray(data.u, dtype=float); x = np.asarray(data.x, dtype=float)
+        assert len(u.shape) == 2, \
+            "Data needs to be shaped as a TxM matrix (T is the number of samples and M is the number of features)"
+        assert len(x.shape) == 2, \
+            "Data needs to be shaped as a TxM matrix (T is the number of samples and M is the number of features)"
+        assert x.shape[0] == u.shape[0], "Input/state data must have the same length"
+        self.dataset = DataDrivenDataset(x[1:], x[:-1], u[:-1], data)
+        self.optimization_problem = None
+        self._drop_native()
+
+    def _drop_native(self):
+        if getattr(self, "_native", None) is not None:
+            self._native.close()
+        self._native = None
+
+    # ---- reference :67-85 ------------------------------------------------------------------------
+    def build_zonotopes(self, zonotopes: SystemZonotopes):
+        X0, W, U, X = zonotopes.X0, zonotopes.W, zonotopes.U, zonotopes.X
+        assert X0.dimension == W.dimension and X0.dimension == self.dim_x and X.dimension == X0.dimension, \
+            "The zonotopes do not have the correct dimension"
+        self.optimization_problem = None
+        self.zonotopes = zonotopes
+        Mw = concatenate_zonotope(W, self.num_samples - 1)
+        self.Mdata = compute_LTI_matrix_zonotope(self.dataset.Xm, self.dataset.Xp, self.dataset.Um, Mw)
+        return self.Mdata
+
+    # ---- reference :87-93 ------------------------------------------------------------------------
+    def compute_theta(self, tol: float = 1e-5, num_max_iterations: int = 20, num_initial_points: int = 10,
+                      K: Optional[np.ndarray] = None) -> Theta:
+        assert self.Mdata is not None, "Mdata is not defined"
+        n = self.dim_x
+        self.theta = _compute_theta(self.Mdata, self.Mdata.center[:, :n], self.Mdata.center[:, n:],
+                                    tol, num_initial_points, num_max_iterations, K=K)
+        return self.theta
+
+    # ---- reference :95-130 -----------------------------------------------------------------------
+    def build_zonotopes_theta(self, zonotopes: SystemZonotopes, tol: float = 1e-5, num_max_iterations: int = 20,
+                              num_initial_points: int = 10, theta: Optional[Theta] = None,
+                              K: Optional[np.ndarray] = None) -> Tuple[Theta, MatrixZonotope]:
+        """As the reference, plus ``theta=`` / ``K=`` to supply the gain as a fixture (the reference's
+        LMI + DCCP/MOSEK synthesis, ``tzddpc/utils.py:60-103``, is out of scope; default is LQR)."""
+        self.build_zonotopes(zonotopes)
+        if theta is not None:
+            self.theta = Theta(np.atleast_2d(np.asarray(theta.K, float)), theta.deltaA, theta.deltaB)
+        else:
+            self.compute_theta(tol, num_max_iterations, num_initial_points, K=K)
+        n = self.dim_x
+        self.MdataK = self.Mdata * np.vstack([np.eye(n), self.theta.K])                    # :119
+        self.Mdelta = self.Mdata + (-1.0 * self.Mdata.center)                               # :122-123
+        self.Mdata = self.Mdata.reduce(1)                                                   # :126-128
+        self.MdataK = self.MdataK.reduce(1)
+        self.Mdelta = self.Mdelta.reduce(1)
+        self._drop_native()
+        return self.theta, self.Mdata
+
+    # ---- reference :132-241 / :243-355 -------------------------------------------------------------
+    def build_problem(self, horizon: int, build_loss: Callable, build_constraints: Optional[Callable] = None, **solver_kwargs):
+        return self._build(None, horizon, build_loss, build_constraints, **solver_kwargs)
+
+    def build_problem_simplified(self, k0: int, horizon: int, build_loss: Callable,
+                                 build_constraints: Optional[Callable] = None, **solver_kwargs):
+        return self._build(int(k0), horizon, build_loss, build_constraints, **solver_kwargs)
+
+    def _build(self, k0, horizon, build_loss, build_constraints, **solver_kwargs):
+        assert build_loss is not None, "Loss function callback cannot be none"
+        n, m = self.dim_x, self.dim_u
+        DK = self.MdataK.single_entry_magnitudes()
+        Dd = self.Mdelta.single_entry_magnitudes()
+        if DK is None or Dd is None:
+            raise StructureError(
+                "MdataK / Mdelta have generators with more than one non-zero entry; only the Girard order-1 boxes that "
+                "build_zonotopes_theta produces (reference tzddpc/tzddpc.py:126-128) are supported by the collapsed tube path")
+        if np.abs(self.Mdelta.center).max(initial=0.0) != 0.0:
+            raise StructureError("Mdelta must have a zero center (reference tzddpc/tzddpc.py:122-123)")
+        A, B = self.Mdata.center[:, :n], self.Mdata.center[:, n:]                             # :163
+        Xi, Ui = self.zonotopes.X.interval, self.zonotopes.U.interval
+        W = self.zonotopes.W
+        qp = build_parametric_qp(A, B, self.MdataK.center, DK, Dd, self.theta.K, W.center, W.generators,
+                                 Xi.left_limit, Xi.right_limit, Ui.left_limit, Ui.right_limit,
+                                 int(horizon), build_loss, build_constraints, k0)
+        self.qp = qp
+        self.horizon = int(horizon)
+        self.k0 = k0
+        # one-sided, equilibrated form for the interior-point kernel
+        fu = np.isfinite(qp.u0); fl = np.isfinite(qp.l0)
+        eq = fu & fl & (qp.u0 == qp.l0) & np.all(qp.Ut == qp.Lt, axis=1)
+        if np.any(eq):
+            raise NotImplementedError("equality constraints from build_constraints are not supported by the HIP solver yet")
+        G = np.vstack([qp.A[fu], -qp.A[fl]])
+        h0 = np.concatenate([qp.u0[fu], -qp.l0[fl]])
+        Ht = np.vstack([qp.Ut[fu], -qp.Lt[fl]])
+        row_of = np.concatenate([np.nonzero(fu)[0], np.nonzero(fl)[0]]).astype(np.int32)
+        q_ref = np.abs(qp.q0) + np.abs(qp.Qt).sum(axis=1)
+        D, E, c = _ruiz(qp.P, G, q_ref)
+        self._scal = (D, E, c)
+        self._row_of = row_of
+        opts = dict(max_iter=int(solver_kwargs.pop("max_iter", 40)), tol=float(solver_kwargs.pop("tol", 1e-10)),
+                    reg=float(solver_kwargs.pop("reg", 1e-12)), step_frac=float(solver_kwargs.pop("step_frac", 0.99)))
+        self._drop_native()
+        self._native = native.Problem(
+            self.device, n=n, m=m, N=int(horizon),
+            P=c * D[:, None] * qp.P * D[None, :], G=E[:, None] * G * D[None, :],
+            q0=c * D * qp.q0, Qt=(c * D)[:, None] * qp.Qt, h0=E * h0, Ht=E[:, None] * Ht,
+            par0=qp.f0, Part=qp.Ft, par_lo=qp.pl, par_hi=qp.pu,
+            cost_scale=c, r0=qp.r0, r1=qp.r1, R2=qp.R2, Dz=D, Phi=qp.Phi, Gam=qp.Gam,
+            nc_rows=qp.nc, row_of=row_of,
+            CK=qp.tube.CK, DK=qp.tube.DK, K=qp.tube.K, pmax=qp.tube.pmax,
+            absCKpow=qp.tube.absCKpow, absKCKpow=qp.tube.absKCKpow, power=qp.tube.power, **opts)
+        self.problem_full = self._native
+        self.optimization_problem = self._native
+        return self._native
+
+    # ---- reference :357-377 ----------------------------------------------------------------------
+    def solve(self, xbar0: np.ndarray, e0: np.ndarray, **solver_kwargs) -> Tuple[float, np.ndarray, np.ndarray, TubeZonotope]:
+        """One MPC step for one trajectory; keyword arguments (``verbose=...``) are accepted and ignored."""
+        if self._native is None:
+            raise Exception("Problem was not built: call build_problem first")
+        v, xbar, cost, status, iters, _ = self._native.solve_batch(np.asarray(xbar0, float).reshape(1, -1),
+                                                                  np.asarray(e0, float).reshape(1, -1))
+        st = int(status[0])
+        if st in (native.TZ_INFEASIBLE,) or not np.isfinite(cost[0]):
+            if st == native.TZ_NUMERICAL:
+                msg = "Error while solving the TZDDPC problem. Details: numerical failure in the interior-point kernel"
+                with open("zpc_logs.txt", "w") as f:                                        # :369-371
+                    print(msg, file=f)
+                raise Exception(msg)
+            raise Exception("Problem is unbounded")                                          # :374-375 (also infeasible)
+        if st == native.TZ_NUMERICAL:
+            msg = "Error while solving the TZDDPC problem. Details: numerical failure in the interior-point kernel"
+            with open("zpc_logs.txt", "w") as f:
+                print(msg, file=f)
+            raise Exception(msg)
+        self.last_status, self.last_iters = st, int(iters[0])
+        return float(cost[0]), v[0], xbar[0], self._ze1(np.asarray(xbar0, float).reshape(-1), np.asarray(e0, float).reshape(-1), v[0][0])
+
+    def _ze1(self, xbar0, e0, v0) -> TubeZonotope:
+        """Literal ``Ze[1] = MdataK * <e0,[0]> + (Mdelta * <[xbar0; v0],[0]> + W)`` (``:172-176, :205``).
+
+        Host numpy, for plotting only (``examples/1.double_integrator_sim.py:89-90``); not on the hot path.
+        """
+        n = self.dim_x
+        Ze0 = Zonotope(e0, np.zeros((n, 1)))
+        XU0 = Zonotope(np.concatenate([xbar0, np.atleast_1d(v0)]), np.zeros((n + self.dim_u, 1)))
+        Z = self.MdataK * Ze0 + (self.Mdelta * XU0 + self.zonotopes.W)
+        return TubeZonotope(Z.Z)
+
+    # ---- batched entry points (what the GPU path is for) -------------------------------------------
+    def solve_batch(self, xbar0: np.ndarray, e0: np.ndarray, want_active: bool = False):
+        """B independent ``solve`` calls in one launch sequence.  Returns dict(cost, v, xbar, status, iters[, active])."""
+        if self._native is None:
+            raise Exception("Problem was not built: call build_problem first")
+        v, xbar, cost, status, iters, active = self._native.solve_batch(xbar0, e0, want_active)
+        out = dict(cost=cost, v=v, xbar=xbar, status=status, iters=iters)
+        if want_active:
+            out["active"] = active
+        return out
+
+    def simulate_batch(self, x0: np.ndarray, noise: np.ndarray, A_true: np.ndarray, B_true: np.ndarray):
+        """Closed loop of ``examples/1.double_integrator_sim.py:75-90`` for B trajectories, T = noise.shape[1] steps."""
+        if self._native is None:
+            raise Exception("Problem was not built: call build_problem first")
+        x, u, cost, status = self._native.simulate_batch(x0, noise, A_true, B_true)
+        return dict(x=x, u=u, cost=cost, status=status)
