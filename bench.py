@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- MPC steps/s of the TZDDPC hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): double integrator (n=2, m=1), horizon N=20,
+full build_problem, complexity-script zonotopes, 1024 closed-loop trajectories PER GPU (weak scaling),
+vertex-of-W noise with PCG64(1000 + global trajectory index).  One "step" = one MPC step of every trajectory of the
+rank: tube propagation + parameter application + interior-point QP solve + recovery + plant update
+(tz_mpc_step), state resident in HBM.  Trajectories are independent: ranks share nothing on the data path; one
+all-gather of (cost, final state) per trajectory closes the timed region (RCCL over xGMI).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (== vector) peak, AMD spec; tools/mfma_f64_rate.hip measures 73 on v_mfma_f64_4x4x4
+
+
+def di_loss(u, x):
+    from tzddpc_amd import cplite as cp
+    cost = 0
+    for i in range(u.shape[0]):
+        cost += cp.norm(x[i, :], p=2) ** 2 + 1e-2 * cp.norm(u[i], p=1)
+    return cost
+
+
+def build_controller(device, horizon):
+    from tzddpc_amd import TZDDPC
+    from tzddpc_amd.harness import generate_trajectories, system
+    A, B, zon, T = system("di_cc")
+    rng = np.random.default_rng(25)
+    ctl = TZDDPC(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, rng), device=device)
+    ctl.build_zonotopes_theta(zon)
+    ctl.build_problem(horizon, di_loss, lambda u, x: [])
+    return ctl, A, B, zon
+
+
+def cpu_baseline(ctl, A, B, zon, horizon, seconds_budget=12.0):
+    """Plain-C oracle (oracle/c/tz_oracle.c) on the host cores: bounded closed-loop sample of the same workload."""
+    from oracle.c_oracle import COracle
+    from tzddpc_amd.dist import vertex_noise
+    co = COracle(ctl.qp)
+    cores = max(1, min(os.cpu_count() or 1, COracle.max_threads(), 16))
+    n = ctl.qp.n
+    Wv = zon.W.compute_vertices()
+    # calibrate on a tiny run, then size the sample to ~seconds_budget of wall time
+    x0 = np.tile(zon.X0.center, (cores, 1))
+    t0 = time.perf_counter(); co.simulate_batch(x0, vertex_noise(Wv, 0, cores, 2), A, B, threads=cores); dt = time.perf_counter() - t0
+    per_step = dt / 2.0                       # wall seconds per (cores trajectories x 1 step)
+    steps = 10
+    traj = int(max(cores, min(1024, cores * max(1, round(seconds_budget / max(per_step * steps, 1e-9))))))
+    x0 = np.tile(zon.X0.center, (traj, 1))
+    noise = vertex_noise(Wv, 0, traj, steps)
+    t0 = time.perf_counter(); out = co.simulate_batch(x0, noise, A, B, threads=cores); dt = time.perf_counter() - t0
+    return {"value": traj * steps / dt, "unit": "MPC steps/s", "cores": cores, "kind": "port",
+            "sample": f"{traj} trajectories x {steps} closed-loop steps of the same DI N={horizon} workload, plain-C oracle with OpenMP over "
+                      f"trajectories, {dt:.1f} s wall, all statuses zero: {bool((out['status'] == 0).all())}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tzddpc_amd.dist import gather_results, shard_range, vertex_noise
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    ctl, A, Bm, zon = build_controller(local_rank, args.horizon)
+    nat = ctl._native
+    n, m = ctl.qp.n, ctl.qp.m
+    Bl = args.batch
+    total = Bl * world
+    lo, hi = shard_range(total, world, rank)
+    assert hi - lo == Bl
+    K, W = args.steps, args.warmup
+    Wv = zon.W.compute_vertices()
+    noise = torch.from_numpy(np.ascontiguousarray(vertex_noise(Wv, lo, Bl, K + W).transpose(1, 0, 2))).to(dev)   # (K+W) x B x n
+    x = torch.from_numpy(np.tile(zon.X0.center, (Bl, 1))).to(dev)
+    xbar = x.clone(); e = torch.zeros_like(x)
+    u = torch.zeros((Bl, m), dtype=torch.float64, device=dev)
+    cost = torch.zeros(Bl, dtype=torch.float64, device=dev)
+    status = torch.zeros(Bl, dtype=torch.int32, device=dev)
+    bad = torch.zeros(Bl, dtype=torch.int32, device=dev)
+    At = torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(dev)
+    Bt = torch.from_numpy(np.ascontiguousarray(Bm, dtype=np.float64)).to(dev)
+    torch.cuda.synchronize()
+
+    def step(t):
+        nat.mpc_step_ptr(Bl, x.data_ptr(), xbar.data_ptr(), e.data_ptr(), noise[t].data_ptr(), At.data_ptr(), Bt.data_ptr(),
+                         u.data_ptr(), cost.data_ptr(), status.data_ptr())
+
+    for t in range(W):
+        step(t)
+    nat.sync()
+    bad |= (status != 0).int()
+    nat.timing_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(); nat.sync()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        step(t)
+    nat.sync()
+    gathered = gather_results(torch.cat([cost[:, None], x], dim=1), total)    # per-trajectory cost + final state only
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ipm_ms, ipm_n = nat.timing_get(1)
+    prep_ms, _ = nat.timing_get(0); fin_ms, _ = nat.timing_get(2); plant_ms, _ = nat.timing_get(3)
+    bad |= (status != 0).int()
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    nbad = bad.sum().to(torch.float64).reshape(1)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nbad, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        # roofline of the dominant kernel (tz_ipm_kernel): useful MFMA flops of the static plan x iterations
+        plan = nat.plan_info()
+        out1 = ctl.solve_batch(xbar.cpu().numpy(), e.cpu().numpy())         # iteration counts of a representative step
+        iters_mean = float(out1["iters"].mean())
+        flop_per_launch = (plan["mfma_gram_per_iter"] + plan["mfma_chol_per_iter"]) * 512.0 * (iters_mean + 1) * Bl
+        avg_ms = ipm_ms / max(ipm_n, 1)
+        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+        line = {
+            "metric": "MPC steps/sec (batched trajectories), double-integrator N=20",
+            "value": total * K / elapsed, "unit": "MPC steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"double integrator n=2 m=1, horizon N={args.horizon}, full build_problem, {Bl} closed-loop trajectories per GPU "
+                                   f"(BASELINE.json configs[1]), complexity-script zonotopes, vertex-of-W noise PCG64(1000+i)",
+                       "trajectories_per_gpu": Bl, "horizon": args.horizon, "nz": ctl.qp.nz, "rows": int(nat.mi),
+                       "ipm_iterations_mean": iters_mean, "unsolved_trajectory_steps": int(nbad.item()),
+                       "kernel_ms_per_step": {"tz_tube+affine": prep_ms / max(ipm_n, 1), "tz_ipm": avg_ms, "tz_finish": fin_ms / max(ipm_n, 1),
+                                              "tz_plant": plant_ms / max(ipm_n, 1)}},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "tz_ipm_kernel", "avg_launch_ms": avg_ms, "launches": int(ipm_n),
+                         "flop_per_launch": flop_per_launch,
+                         "note": "useful v_mfma_f64_4x4x4 flops of the static plan (Gram G'WG + Cholesky trailing updates) x (iterations+1) x trajectories"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(ctl, A, Bm, zon, args.horizon)
+            except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "MPC steps/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

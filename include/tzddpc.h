@@ -163,10 +163,12 @@ int tz_mpc_step(tz_problem* p, int32_t B, double* x, double* xbar, double* e, co
  * kernel ids: 0 = tz_prepare, 1 = tz_ipm, 2 = tz_finish, 3 = tz_plant_step */
 int tz_timing_enable(tz_problem* p, int enable);
 int tz_timing_get(tz_problem* p, int kernel, double* total_ms, int64_t* launches);
-/* algorithmic work of the last tz_ipm launch: MFMA (4x4x4 f64) instructions issued per interior-point
- * iteration by one trajectory (Gram formation + Cholesky trailing updates), from the static plan. */
+/* Static plan of tz_ipm for one trajectory and one interior-point iteration: number of
+ * v_mfma_f64_4x4x4 instructions that carry useful tiles in the Gram formation (G'WG, block-sparse) and in
+ * the Cholesky trailing updates, the number actually issued (padding included), LDS bytes per workgroup
+ * and bytes of the packed constraint patches. */
 int tz_ipm_plan_info(tz_problem* p, int64_t* mfma_gram_per_iter, int64_t* mfma_chol_per_iter,
-                     int64_t* lds_bytes, int64_t* patch_bytes);
+                     int64_t* mfma_issued_per_iter, int64_t* lds_bytes, int64_t* patch_bytes);
 
 /* Test hook: copy device-side intermediates of trajectory `b` of the last solve to the host.
  * what: 0 = theta (ntheta), 1 = q (nz), 2 = h (mi), 3 = x (nz), 4 = s (mi), 5 = lambda (mi) */

@@ -1,0 +1,349 @@
+/*
+ * tz_oracle.c -- plain-C restatement of the per-step numeric path.  ORACLE / TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the product
+ * (tzddpc_amd/) never does.  PARITY UNPINNED: the reference has no fixtures for this path and cannot
+ * be run here (oracle/__init__.py).
+ *
+ * What it restates (reference rssalessio/TZDDPC):
+ *   tube propagation from e0            tzddpc/tzddpc.py:172-181, 191-192 (numeric content)
+ *   parameter application               tzddpc/tzddpc.py:364-365
+ *   the conic solve                     tzddpc/tzddpc.py:367  (an interior-point solver in the reference too)
+ *   returned v, xbar, objective         tzddpc/tzddpc.py:377
+ *   plant / error update                examples/1.double_integrator_sim.py:83-87
+ *
+ * Input is the UNSCALED two-sided parametric QP  min 1/2 z'Pz + q(theta)'z,  l(theta) <= A z <= u(theta);
+ * this file does its own equilibration, one-sided conversion, dense Cholesky (no blocking, no MFMA
+ * structure) and Mehrotra predictor-corrector, so agreement with the HIP kernels is a real check.
+ * OpenMP over trajectories (threads argument); scalar code otherwise.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct tzo_desc {
+  int32_t n, m, N, nz, nc, ntheta, npar;
+  const double *P, *A;            /* nz x nz, nc x nz */
+  const double *q0, *Qt;          /* nz, nz x ntheta */
+  const double *l0, *Lt, *u0, *Ut;/* nc, nc x ntheta (entries of l0/u0 may be -/+inf) */
+  const double *f0, *Ft, *pl, *pu;/* parameter-only rows */
+  double r0; const double *r1, *R2;
+  const double *Phi, *Gam;        /* (N+1)n x n, (N+1)n x N m */
+  const double *CK, *DK, *K;      /* n x n, n x n, m x n */
+  int32_t pmax; const double *absCK, *absKCK; const int32_t *power;
+  int32_t max_iter; double tol, reg, step_frac;
+} tzo_desc;
+
+typedef struct {
+  int nz, mi;
+  double *P, *G, *D, *E; double c;
+  int *row, *sgn;                 /* one-sided row -> (two-sided row, +1 upper / -1 lower) */
+} setup_t;
+
+static void ruiz(int nz, int mi, double* P, double* G, double* D, double* E, int iters) {
+  for (int i = 0; i < nz; ++i) D[i] = 1.0;
+  for (int r = 0; r < mi; ++r) E[r] = 1.0;
+  double* d = (double*)malloc(sizeof(double) * nz);
+  double* e = (double*)malloc(sizeof(double) * mi);
+  for (int it = 0; it < iters; ++it) {
+    for (int c = 0; c < nz; ++c) {
+      double mx = 0;
+      for (int r = 0; r < nz; ++r) mx = fmax(mx, fabs(P[r * nz + c]));
+      for (int r = 0; r < mi; ++r) mx = fmax(mx, fabs(G[r * nz + c]));
+      d[c] = 1.0 / sqrt(mx < 1e-8 ? 1.0 : mx);
+    }
+    for (int r = 0; r < mi; ++r) {
+      double mx = 0;
+      for (int c = 0; c < nz; ++c) mx = fmax(mx, fabs(G[r * nz + c]));
+      e[r] = 1.0 / sqrt(mx < 1e-8 ? 1.0 : mx);
+    }
+    for (int r = 0; r < nz; ++r) for (int c = 0; c < nz; ++c) P[r * nz + c] *= d[r] * d[c];
+    for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) G[r * nz + c] *= e[r] * d[c];
+    for (int c = 0; c < nz; ++c) D[c] *= d[c];
+    for (int r = 0; r < mi; ++r) E[r] *= e[r];
+  }
+  free(d); free(e);
+}
+
+static setup_t* make_setup(const tzo_desc* d) {
+  setup_t* S = (setup_t*)calloc(1, sizeof(setup_t));
+  int nz = d->nz, nc = d->nc, mi = 0;
+  for (int r = 0; r < nc; ++r) { if (isfinite(d->u0[r])) mi++; if (isfinite(d->l0[r])) mi++; }
+  S->nz = nz; S->mi = mi;
+  S->P = (double*)malloc(sizeof(double) * nz * nz); memcpy(S->P, d->P, sizeof(double) * nz * nz);
+  S->G = (double*)malloc(sizeof(double) * mi * nz);
+  S->D = (double*)malloc(sizeof(double) * nz); S->E = (double*)malloc(sizeof(double) * mi);
+  S->row = (int*)malloc(sizeof(int) * mi); S->sgn = (int*)malloc(sizeof(int) * mi);
+  int k = 0;
+  for (int r = 0; r < nc; ++r) if (isfinite(d->u0[r])) { S->row[k] = r; S->sgn[k] = 1; for (int c = 0; c < nz; ++c) S->G[k * nz + c] = d->A[r * nz + c]; k++; }
+  for (int r = 0; r < nc; ++r) if (isfinite(d->l0[r])) { S->row[k] = r; S->sgn[k] = -1; for (int c = 0; c < nz; ++c) S->G[k * nz + c] = -d->A[r * nz + c]; k++; }
+  ruiz(nz, mi, S->P, S->G, S->D, S->E, 15);
+  double pn = 0, qn = 0;
+  for (int i = 0; i < nz * nz; ++i) pn = fmax(pn, fabs(S->P[i]));
+  for (int c = 0; c < nz; ++c) {
+    double a = fabs(d->q0[c]);
+    for (int t = 0; t < d->ntheta; ++t) a += fabs(d->Qt[c * d->ntheta + t]);
+    qn = fmax(qn, S->D[c] * a);
+  }
+  S->c = 1.0 / fmax(fmax(pn, qn), 1e-300);
+  for (int i = 0; i < nz * nz; ++i) S->P[i] *= S->c;
+  return S;
+}
+
+static void free_setup(setup_t* S) { free(S->P); free(S->G); free(S->D); free(S->E); free(S->row); free(S->sgn); free(S); }
+
+/* theta = [xbar0 | |xbar0| | (c_k, rho^x_k, rho^u_k)_k]: literal restatement of the collapsed recursion */
+static void tube_theta(const tzo_desc* d, const double* xbar0, const double* e0, double* th, double* ws) {
+  int n = d->n, m = d->m, pm = d->pmax;
+  double* c = ws;                       /* (pm+1) x n */
+  double* beta = c + (pm + 1) * n;      /* pm x n */
+  double* rx = beta + (pm > 0 ? pm : 1) * n;   /* (pm+1) x n */
+  double* ru = rx + (pm + 1) * n;       /* (pm+1) x m */
+  for (int i = 0; i < n; ++i) { th[i] = xbar0[i]; th[n + i] = fabs(xbar0[i]); c[i] = e0[i]; rx[i] = 0; }
+  for (int j = 0; j < m; ++j) ru[j] = 0;
+  for (int p = 0; p < pm; ++p) {
+    for (int i = 0; i < n; ++i) {
+      double a = 0; for (int j = 0; j < n; ++j) a += d->DK[i * n + j] * (fabs(c[p * n + j]) + rx[p * n + j]);
+      beta[p * n + i] = a;
+      double b = 0; for (int j = 0; j < n; ++j) b += d->CK[i * n + j] * c[p * n + j];
+      c[(p + 1) * n + i] = b;
+    }
+    for (int i = 0; i < n; ++i) {
+      double a = 0;
+      for (int l = 0; l <= p; ++l) for (int j = 0; j < n; ++j) a += d->absCK[((p - l) * n + i) * n + j] * beta[l * n + j];
+      rx[(p + 1) * n + i] = a;
+    }
+    for (int i = 0; i < m; ++i) {
+      double a = 0;
+      for (int l = 0; l <= p; ++l) for (int j = 0; j < n; ++j) a += d->absKCK[((p - l) * m + i) * n + j] * beta[l * n + j];
+      ru[(p + 1) * m + i] = a;
+    }
+  }
+  int blk = 2 * n + m;
+  for (int k = 0; k < d->N; ++k) {
+    int p = d->power[k];
+    double* dst = th + 2 * n + k * blk;
+    for (int i = 0; i < n; ++i) { dst[i] = c[p * n + i]; dst[n + i] = rx[p * n + i]; }
+    for (int j = 0; j < m; ++j) dst[2 * n + j] = ru[p * m + j];
+  }
+}
+
+static int cholesky(int n, double* H) {   /* lower, in place, unblocked */
+  for (int j = 0; j < n; ++j) {
+    double dg = H[j * n + j];
+    for (int k = 0; k < j; ++k) dg -= H[j * n + k] * H[j * n + k];
+    if (!(dg > 0)) return 0;
+    dg = sqrt(dg); H[j * n + j] = dg;
+    for (int i = j + 1; i < n; ++i) {
+      double a = H[i * n + j];
+      for (int k = 0; k < j; ++k) a -= H[i * n + k] * H[j * n + k];
+      H[i * n + j] = a / dg;
+    }
+  }
+  return 1;
+}
+static void chol_solve(int n, const double* L, double* x) {
+  for (int i = 0; i < n; ++i) { double a = x[i]; for (int k = 0; k < i; ++k) a -= L[i * n + k] * x[k]; x[i] = a / L[i * n + i]; }
+  for (int i = n - 1; i >= 0; --i) { double a = x[i]; for (int k = i + 1; k < n; ++k) a -= L[k * n + i] * x[k]; x[i] = a / L[i * n + i]; }
+}
+
+static void form_H(const setup_t* S, const double* w, double reg, double* H, double* GW) {
+  int nz = S->nz, mi = S->mi;
+  for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) GW[r * nz + c] = S->G[r * nz + c] * w[r];
+  for (int i = 0; i < nz; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double a = S->P[i * nz + j];
+      for (int r = 0; r < mi; ++r) a += GW[r * nz + i] * S->G[r * nz + j];
+      H[i * nz + j] = a;
+    }
+  for (int i = 0; i < nz; ++i) H[i * nz + i] += reg;
+}
+
+static double max_step(int n, const double* v, const double* dv) {
+  double a = 1e300;
+  for (int i = 0; i < n; ++i) if (dv[i] < 0) a = fmin(a, -v[i] / dv[i]);
+  return a;
+}
+
+/* status: 0 solved, 1 max_iter, 2 numerical, 3 infeasible */
+static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const double* h, double* x, double* s, double* lam, int* iters, double* wk) {
+  int nz = S->nz, mi = S->mi;
+  double* H = wk; double* GW = H + nz * nz;
+  double* w = GW + mi * nz; double* rd = w + mi; double* rp = rd + nz; double* r1 = rp + mi;
+  double* dx = r1 + nz; double* ds = dx + nz; double* dl = ds + mi; double* t1 = dl + mi; double* gx = t1 + mi; double* gdx = gx + mi; double* rc = gdx + mi;
+  for (int r = 0; r < mi; ++r) w[r] = 1.0;
+  form_H(S, w, d->reg, H, GW);
+  if (!cholesky(nz, H)) return 2;
+  for (int c = 0; c < nz; ++c) { double a = -q[c]; for (int r = 0; r < mi; ++r) a += S->G[r * nz + c] * h[r]; x[c] = a; }
+  chol_solve(nz, H, x);
+  double rmin = 1e300;
+  for (int r = 0; r < mi; ++r) { double a = 0; for (int c = 0; c < nz; ++c) a += S->G[r * nz + c] * x[c]; gx[r] = a; rmin = fmin(rmin, h[r] - a); }
+  double shift = rmin <= 1e-8 ? fmax(0.0, 1.0 - rmin) : 0.0;
+  for (int r = 0; r < mi; ++r) { s[r] = h[r] - gx[r] + shift; lam[r] = 1.0; }
+  double scd = 0, scp = 0;
+  for (int c = 0; c < nz; ++c) scd = fmax(scd, fabs(q[c]));
+  for (int r = 0; r < mi; ++r) scp = fmax(scp, fabs(h[r]));
+  scd += 1.0; scp += 1.0;
+  int it;
+  for (it = 0; it < d->max_iter; ++it) {
+    double nrd = 0, nrp = 0, mu = 0;
+    for (int c = 0; c < nz; ++c) {
+      double a = q[c];
+      for (int k = 0; k < nz; ++k) a += S->P[c * nz + k] * x[k];
+      for (int r = 0; r < mi; ++r) a += S->G[r * nz + c] * lam[r];
+      rd[c] = a; nrd = fmax(nrd, fabs(a));
+    }
+    for (int r = 0; r < mi; ++r) { rp[r] = gx[r] + s[r] - h[r]; nrp = fmax(nrp, fabs(rp[r])); mu += s[r] * lam[r]; }
+    mu /= mi; nrd /= scd; nrp /= scp;
+    *iters = it;
+    if (nrd <= d->tol && nrp <= d->tol && mu <= d->tol) return 0;
+    if (mu <= 1e-3 * d->tol) return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 3;
+    if (!(mu == mu) || !(nrd == nrd) || mu > 1e200) return 2;
+    for (int r = 0; r < mi; ++r) w[r] = lam[r] / s[r];
+    form_H(S, w, d->reg, H, GW);
+    if (!cholesky(nz, H)) return 2;
+    /* predictor */
+    for (int r = 0; r < mi; ++r) t1[r] = w[r] * rp[r] - lam[r];
+    for (int c = 0; c < nz; ++c) { double a = -rd[c]; for (int r = 0; r < mi; ++r) a -= S->G[r * nz + c] * t1[r]; dx[c] = a; }
+    chol_solve(nz, H, dx);
+    for (int r = 0; r < mi; ++r) { double a = 0; for (int c = 0; c < nz; ++c) a += S->G[r * nz + c] * dx[c]; ds[r] = -rp[r] - a; dl[r] = -lam[r] - w[r] * ds[r]; }
+    double ap = fmin(1.0, max_step(mi, s, ds)), ad = fmin(1.0, max_step(mi, lam, dl));
+    double muaff = 0;
+    for (int r = 0; r < mi; ++r) muaff += (s[r] + ap * ds[r]) * (lam[r] + ad * dl[r]);
+    muaff /= mi;
+    double sigma = muaff / mu; sigma = sigma * sigma * sigma;
+    /* corrector */
+    for (int r = 0; r < mi; ++r) { rc[r] = s[r] * lam[r] + ds[r] * dl[r] - sigma * mu; t1[r] = (-rc[r] + lam[r] * rp[r]) / s[r]; }
+    for (int c = 0; c < nz; ++c) { double a = -rd[c]; for (int r = 0; r < mi; ++r) a -= S->G[r * nz + c] * t1[r]; dx[c] = a; }
+    chol_solve(nz, H, dx);
+    for (int r = 0; r < mi; ++r) { double a = 0; for (int c = 0; c < nz; ++c) a += S->G[r * nz + c] * dx[c]; gdx[r] = a; ds[r] = -rp[r] - a; dl[r] = (-rc[r] - lam[r] * ds[r]) / s[r]; }
+    double alpha = fmin(1.0, d->step_frac * fmin(max_step(mi, s, ds), max_step(mi, lam, dl)));
+    for (int c = 0; c < nz; ++c) x[c] += alpha * dx[c];
+    for (int r = 0; r < mi; ++r) { s[r] += alpha * ds[r]; lam[r] += alpha * dl[r]; gx[r] += alpha * gdx[r]; }
+  }
+  *iters = it;
+  return 1;
+}
+
+static size_t work_doubles(const tzo_desc* d, const setup_t* S) {
+  size_t nz = S->nz, mi = S->mi;
+  return nz * nz + mi * nz + 9 * mi + 4 * nz /* ipm */ + d->ntheta + nz + 3 * mi /* theta, q, h, s, lam */ + nz
+         + (size_t)(d->pmax + 2) * (3 * d->n + d->m) + 64;
+}
+
+static void solve_one(const tzo_desc* d, const setup_t* S, const double* xbar0, const double* e0,
+                      double* v, double* xbar, double* cost, int32_t* status, int32_t* iters, uint8_t* active, double* wk) {
+  int nz = S->nz, mi = S->mi, n = d->n, m = d->m, N = d->N, nt = d->ntheta;
+  double* th = wk; double* q = th + nt; double* h = q + nz; double* x = h + mi; double* s = x + nz; double* lam = s + mi;
+  double* tws = lam + mi; double* iw = tws + (size_t)(d->pmax + 2) * (3 * n + m);
+  tube_theta(d, xbar0, e0, th, tws);
+  int feas = 1;
+  for (int r = 0; r < d->npar; ++r) {
+    double a = d->f0[r]; for (int t = 0; t < nt; ++t) a += d->Ft[r * nt + t] * th[t];
+    if (!(a >= d->pl[r] - 1e-9) || !(a <= d->pu[r] + 1e-9)) feas = 0;
+  }
+  int nv = N * m, it = 0, st = 3;
+  if (feas) {
+    for (int c = 0; c < nz; ++c) { double a = d->q0[c]; for (int t = 0; t < nt; ++t) a += d->Qt[c * nt + t] * th[t]; q[c] = S->c * S->D[c] * a; }
+    for (int k = 0; k < mi; ++k) {
+      int r = S->row[k]; const double* M = S->sgn[k] > 0 ? d->Ut : d->Lt; double a = S->sgn[k] > 0 ? d->u0[r] : d->l0[r];
+      for (int t = 0; t < nt; ++t) a += M[r * nt + t] * th[t];
+      h[k] = S->E[k] * S->sgn[k] * a;
+    }
+    st = ipm(d, S, q, h, x, s, lam, &it, iw);
+  } else { for (int c = 0; c < nz; ++c) x[c] = 0; }
+  *status = st; if (iters) *iters = it;
+  double obj = 0;
+  for (int c = 0; c < nz; ++c) { double px = 0; for (int k = 0; k < nz; ++k) px += S->P[c * nz + k] * x[k]; obj += x[c] * (0.5 * px + q[c]); }
+  double r = d->r0;
+  for (int i = 0; i < n; ++i) { r += d->r1[i] * xbar0[i]; for (int j = 0; j < n; ++j) r += xbar0[i] * d->R2[i * n + j] * xbar0[j]; }
+  *cost = (st == 0 || st == 1) ? obj / S->c + r : INFINITY;
+  for (int c = 0; c < nv; ++c) v[c] = S->D[c] * x[c];
+  for (int rr = 0; rr < (N + 1) * n; ++rr) {
+    double a = 0; for (int j = 0; j < n; ++j) a += d->Phi[rr * n + j] * xbar0[j];
+    for (int c = 0; c < nv; ++c) a += d->Gam[rr * nv + c] * v[c];
+    xbar[rr] = a;
+  }
+  if (active) {
+    memset(active, 0, (size_t)d->nc);
+    if (feas) for (int k = 0; k < mi; ++k) if (s[k] < lam[k]) active[S->row[k]] = 1;
+  }
+}
+
+int tzo_solve_batch(const tzo_desc* d, int B, const double* xbar0, const double* e0, double* v, double* xbar,
+                    double* cost, int32_t* status, int32_t* iters, uint8_t* active, int threads) {
+  setup_t* S = make_setup(d);
+  size_t wd = work_doubles(d, S);
+  int n = d->n, m = d->m, N = d->N;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#endif
+  {
+    double* wk = (double*)malloc(sizeof(double) * wd);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+    for (int b = 0; b < B; ++b)
+      solve_one(d, S, xbar0 + (size_t)b * n, e0 + (size_t)b * n, v + (size_t)b * N * m, xbar + (size_t)b * (N + 1) * n,
+                cost + b, status + b, iters ? iters + b : NULL, active ? active + (size_t)b * d->nc : NULL, wk);
+    free(wk);
+  }
+  free_setup(S);
+  return 0;
+}
+
+/* closed loop, examples/1.double_integrator_sim.py:75-90 */
+int tzo_simulate_batch(const tzo_desc* d, int B, int T, const double* x0, const double* noise, const double* At, const double* Bt,
+                       double* x_traj, double* u_traj, double* cost, int32_t* status, int threads) {
+  setup_t* S = make_setup(d);
+  size_t wd = work_doubles(d, S);
+  int n = d->n, m = d->m, N = d->N;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#endif
+  {
+    double* wk = (double*)malloc(sizeof(double) * wd);
+    double* v = (double*)malloc(sizeof(double) * N * m);
+    double* xb = (double*)malloc(sizeof(double) * (N + 1) * n);
+    double x[16], xbar[16], e[16], u[8], xn[16];
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+    for (int b = 0; b < B; ++b) {
+      int32_t sticky = 0;
+      for (int i = 0; i < n; ++i) { x[i] = x0[(size_t)b * n + i]; xbar[i] = x[i]; e[i] = 0; x_traj[((size_t)b * (T + 1)) * n + i] = x[i]; }
+      for (int t = 0; t < T; ++t) {
+        int32_t st, it; double c;
+        solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk);
+        if (!sticky && st) sticky = st;
+        if (cost) cost[(size_t)b * T + t] = c;
+        for (int j = 0; j < m; ++j) { double a = v[j]; for (int i = 0; i < n; ++i) a += d->K[j * n + i] * e[i]; u[j] = a; u_traj[((size_t)b * T + t) * m + j] = a; }
+        for (int i = 0; i < n; ++i) {
+          double a = noise[((size_t)b * T + t) * n + i];
+          for (int j = 0; j < n; ++j) a += At[i * n + j] * x[j];
+          for (int j = 0; j < m; ++j) a += Bt[i * m + j] * u[j];
+          xn[i] = a;
+        }
+        for (int i = 0; i < n; ++i) { x[i] = xn[i]; xbar[i] = xb[n + i]; e[i] = x[i] - xbar[i]; x_traj[((size_t)b * (T + 1) + t + 1) * n + i] = x[i]; }
+      }
+      status[b] = sticky;
+    }
+    free(wk); free(v); free(xb);
+  }
+  free_setup(S);
+  return 0;
+}
+
+int tzo_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,104 @@
+"""Shared test helpers: the reference examples' callbacks written against cplite, system construction."""
+import numpy as np
+
+from tzddpc_amd import cplite as cp
+
+
+def loss_di(u, x):            # reference examples/1.double_integrator_sim.py:22-28
+    cost = 0
+    for i in range(u.shape[0]):
+        cost += cp.norm(x[i, :], p=2) ** 2 + 1e-2 * cp.norm(u[i], p=1)
+    return cost
+
+
+def loss_pulley(u, y):        # reference examples/2.pulley_sim.py:17-22
+    cost = 0
+    for i in range(u.shape[0]):
+        cost += cp.norm(y[i, 0] - 1, p=2)
+    return cost
+
+
+def loss_dim5(u, x):          # reference examples/3.5dimsystem_sim.py:14-20
+    cost = 0
+    for i in range(u.shape[0]):
+        cost += 1e9 * cp.norm(x[i, 1] - 2, p=2) + 1e-1 * cp.norm(u[i], p=2)
+    return cost
+
+
+def cons_dim5(u, x):          # reference examples/3.5dimsystem_sim.py:23-26
+    return [x[:, 1] <= 10, x[:, 1] >= 2]
+
+
+def nocons(u, x):
+    return []
+
+
+CASES = {
+    # name: (system, loss, constraints, horizon, k0)
+    "di_n2": ("di_sim", loss_di, nocons, 2, None),
+    "di_n5": ("di_cc", loss_di, nocons, 5, None),
+    "di_n20": ("di_cc", loss_di, nocons, 20, None),
+    "di_n20_k1": ("di_cc", loss_di, nocons, 20, 1),
+    "pulley_n10": ("pulley", loss_pulley, nocons, 10, None),
+    "dim5_n20": ("dim5_w001", loss_dim5, cons_dim5, 20, None),
+}
+
+
+def identified_qp(case, seed=25):
+    """Host-only: data -> Mdata -> collapsed parametric QP, without touching the GPU."""
+    from tzddpc_amd import TZDDPC
+    from tzddpc_amd.builder import build_parametric_qp
+    from tzddpc_amd.harness import generate_trajectories, system
+    sysname, loss, cons, N, k0 = CASES[case]
+    A, B, zon, T = system(sysname)
+    rng = np.random.default_rng(seed)
+    ctl = TZDDPC.__new__(TZDDPC)
+    ctl.device = 0; ctl._native = None; ctl.qp = None
+    ctl.update_identification_data(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, rng))
+    ctl.build_zonotopes_theta(zon)
+    n = ctl.dim_x
+    Xi, Ui = zon.X.interval, zon.U.interval
+    qp = build_parametric_qp(ctl.Mdata.center[:, :n], ctl.Mdata.center[:, n:], ctl.MdataK.center,
+                             ctl.MdataK.single_entry_magnitudes(), ctl.Mdelta.single_entry_magnitudes(), ctl.theta.K,
+                             zon.W.center, zon.W.generators, Xi.left_limit, Xi.right_limit, Ui.left_limit, Ui.right_limit,
+                             N, loss, cons, k0)
+    return ctl, qp, (A, B, zon)
+
+
+def gpu_controller(case, seed=25):
+    from tzddpc_amd import TZDDPC
+    from tzddpc_amd.harness import generate_trajectories, system
+    sysname, loss, cons, N, k0 = CASES[case]
+    A, B, zon, T = system(sysname)
+    rng = np.random.default_rng(seed)
+    ctl = TZDDPC(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, rng))
+    ctl.build_zonotopes_theta(zon)
+    if k0 is None:
+        ctl.build_problem(N, loss, cons)
+    else:
+        ctl.build_problem_simplified(k0, N, loss, cons)
+    return ctl, (A, B, zon)
+
+
+def sample_params(zon, n, B, seed=7, e_scale=0.02, x_scale=0.05):
+    rng = np.random.default_rng(seed)
+    x0 = np.tile(zon.X0.center, (B, 1)) + x_scale * rng.standard_normal((B, n))
+    e0 = e_scale * rng.standard_normal((B, n))
+    e0[0] = 0.0
+    return x0, e0
+
+
+def oracle_solution(qp, x0, e0, tol=1e-12):
+    """High-accuracy reference for one (xbar0, e0): numpy interior point + KKT certificate."""
+    from oracle.qp_ipm import solve_qp
+    from tzddpc_amd.builder import theta_reference
+    th = theta_reference(qp, x0, e0)
+    ql = qp.q0 + qp.Qt @ th; ll = qp.l0 + qp.Lt @ th; ul = qp.u0 + qp.Ut @ th
+    r = solve_qp(qp.P, ql, qp.A, ll, ul, tol=tol)
+    nv = qp.N * qp.m
+    v = r.x[:nv].reshape(qp.N, qp.m)
+    xbar = (qp.Phi @ x0 + qp.Gam @ r.x[:nv]).reshape(qp.N + 1, qp.n)
+    cost = r.obj + qp.r0 + qp.r1 @ x0 + x0 @ qp.R2 @ x0
+    slack = np.minimum(np.where(np.isfinite(ul), ul - qp.A @ r.x, np.inf), np.where(np.isfinite(ll), qp.A @ r.x - ll, np.inf))
+    active = slack < np.abs(r.y)
+    return dict(v=v, xbar=xbar, cost=cost, status=r.status, cert=r.cert, active=active, y=r.y, slack=slack)

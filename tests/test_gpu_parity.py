@@ -1,0 +1,135 @@
+"""-m gpu: the HIP path (through the C-ABI) against the oracle, the golden fixtures and domain properties."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REL = 1e-6          # north_star tolerance: state / input trajectories within 1e-6 relative
+
+
+def _ctl_from_golden(case):
+    from tzddpc_amd import TZDDPC, Data, Theta
+    from tzddpc_amd.harness import system
+    g = np.load(os.path.join(GOLD, f"{case}.npz"))
+    sysname, loss, cons, N, k0 = common.CASES[case]
+    A, B, zon, T = system(sysname)
+    ctl = TZDDPC(Data(g["data_u"], g["data_x"]))
+    ctl.build_zonotopes_theta(zon, theta=Theta(g["K"], np.zeros_like(A), np.zeros_like(B)))
+    if k0 is None:
+        ctl.build_problem(N, loss, cons)
+    else:
+        ctl.build_problem_simplified(k0, N, loss, cons)
+    return ctl, g, (A, B, zon)
+
+
+@pytest.mark.parametrize("case", ["di_n2", "di_n5", "di_n20", "di_n20_k1", "pulley_n10", "dim5_n20"])
+def test_golden_parity(built, case):
+    ctl, g, _ = _ctl_from_golden(case)
+    out = ctl.solve_batch(g["x0"], g["e0"], want_active=True)
+    assert (out["status"] == 0).all(), out["status"]
+    scale = 1.0 + np.abs(g["xbar"]).max()
+    for b in range(4):
+        assert abs(out["cost"][b] - g["cost"][b]) <= 1e-7 * (1 + abs(g["cost"][b]))
+        np.testing.assert_allclose(out["v"][b, 0], g["v"][b, 0], atol=REL * (1 + np.abs(g["v"][b]).max()))   # consumed input
+        np.testing.assert_allclose(out["xbar"][b, 1], g["xbar"][b, 1], atol=REL * scale)                        # consumed state
+        # active set: identical wherever the oracle's complementarity is not borderline
+        slack, y = g["slack"][b], np.abs(g["y"][b])
+        clear = (np.maximum(slack, y) > 1e-8) & ((slack < 1e-2 * y) | (y < 1e-2 * slack))
+        assert np.array_equal(out["active"][b].astype(bool)[clear], g["active"][b][clear])
+    if case.startswith("di_"):       # strictly convex in xbar_1..xbar_{N-1}: whole nominal trajectory is unique there
+        N = common.CASES[case][3]
+        np.testing.assert_allclose(out["xbar"][:, :N], g["xbar"][:, :N], atol=5e-6 * scale)
+
+
+def test_full_size_against_c_oracle(built):
+    """BASELINE config 2 size: 1024 trajectories, N = 20, every trajectory against the plain-C restatement."""
+    from oracle.c_oracle import COracle
+    ctl, (A, B, zon) = common.gpu_controller("di_n20")
+    x0, e0 = common.sample_params(zon, 2, 1024, seed=3, e_scale=0.03, x_scale=0.3)
+    out = ctl.solve_batch(x0, e0, want_active=True)
+    ref = COracle(ctl.qp).solve_batch(x0, e0, threads=16, want_active=True)
+    assert (out["status"] == 0).all() and (ref["status"] == 0).all()
+    assert np.abs(out["cost"] - ref["cost"]).max() <= 1e-7 * (1 + np.abs(ref["cost"]).max())
+    assert np.abs(out["v"][:, 0] - ref["v"][:, 0]).max() <= REL * (1 + np.abs(ref["v"]).max())
+    assert np.abs(out["xbar"][:, 1] - ref["xbar"][:, 1]).max() <= REL * (1 + np.abs(ref["xbar"]).max())
+    agree = (out["active"] == ref["active"]).mean()
+    assert agree > 0.999, agree
+    # size-independent properties: the returned nominal trajectory obeys the data-center dynamics (reference :166-170)
+    n = 2
+    Ah, Bh = ctl.Mdata.center[:, :n], ctl.Mdata.center[:, n:]
+    pred = np.einsum("ij,bkj->bki", Ah, out["xbar"][:, :-1]) + np.einsum("ij,bkj->bki", Bh, out["v"])
+    np.testing.assert_allclose(out["xbar"][:, 1:], pred, atol=1e-9)
+    np.testing.assert_allclose(out["xbar"][:, 0], x0, atol=0)
+
+
+def test_determinism_and_batch_independence(built):
+    ctl, (A, B, zon) = common.gpu_controller("di_n20")
+    x0, e0 = common.sample_params(zon, 2, 257, seed=5)
+    a = ctl.solve_batch(x0, e0)
+    b = ctl.solve_batch(x0, e0)
+    for k in ("v", "xbar", "cost"):
+        assert np.array_equal(a[k], b[k])                       # same inputs -> bitwise same outputs
+    idx = np.array([200, 3, 77, 256, 0])
+    c = ctl.solve_batch(x0[idx], e0[idx])
+    for k in ("v", "xbar", "cost"):
+        assert np.array_equal(c[k], a[k][idx])                  # trajectories are independent units (shardable)
+    one = ctl.solve_batch(x0[:1], e0[:1])
+    assert np.array_equal(one["v"], a["v"][:1])
+
+
+def test_solve_api_matches_reference_surface(built):
+    ctl, (A, B, zon) = common.gpu_controller("di_n2")
+    xbar0 = zon.X0.center.copy(); e0 = np.zeros(2)
+    result, v, xbark, Zek = ctl.solve(xbar0, e0, verbose=False)
+    assert isinstance(result, float) and v.shape == (2, 1) and xbark.shape == (3, 2)
+    Z = Zek.Z.value                                             # examples/1.double_integrator_sim.py:89-90
+    assert Z.shape == (2, 1 + 24)                               # Gamma_1 = 24 for the double integrator
+    ref = common.oracle_solution(ctl.qp, xbar0, e0)
+    assert abs(result - ref["cost"]) <= 1e-8 * (1 + abs(ref["cost"]))
+    # interval hull of the literal Ze[1] equals the collapsed radius used in the constraints
+    from tzddpc_amd.builder import theta_reference
+    rad = np.abs(Z[:, 1:]).sum(axis=1)
+    assert np.all(np.isfinite(rad)) and np.all(rad > 0)
+    with pytest.raises(Exception, match="unbounded"):           # reference :374-375 (also raised for infeasible)
+        ctl.solve(np.array([50.0, 0.0]), e0)
+
+
+def test_closed_loop_golden_and_c_oracle(built):
+    from oracle.c_oracle import COracle
+    ctl, g, (A, B, zon) = _ctl_from_golden("di_n2")
+    gl = np.load(os.path.join(GOLD, "di_n2_closed_loop.npz"))
+    sim = ctl.simulate_batch(gl["x0"], gl["noise"], A, B)
+    assert (sim["status"] == 0).all()
+    np.testing.assert_allclose(sim["x"], gl["x"], atol=REL * (1 + np.abs(gl["x"]).max()))
+    np.testing.assert_allclose(sim["u"], gl["u"], atol=REL * 10)
+    # longer horizon, more trajectories, against the plain-C closed loop
+    from tzddpc_amd.dist import vertex_noise
+    ctl2, (A, B, zon) = common.gpu_controller("di_n20")
+    noise = vertex_noise(zon.W.compute_vertices(), 0, 64, 15)
+    x0 = np.tile(zon.X0.center, (64, 1))
+    s1 = ctl2.simulate_batch(x0, noise, A, B)
+    s2 = COracle(ctl2.qp).simulate_batch(x0, noise, A, B, threads=16)
+    assert (s1["status"] == 0).all() and (s2["status"] == 0).all()
+    np.testing.assert_allclose(s1["x"], s2["x"], atol=2e-6 * (1 + np.abs(s2["x"]).max()))
+    Xi = zon.X.interval
+    assert np.all(s1["x"] >= Xi.left_limit - 1e-9) and np.all(s1["x"] <= Xi.right_limit + 1e-9)
+
+
+def test_device_pointer_path_equals_host_path(built):
+    import torch
+    ctl, (A, B, zon) = common.gpu_controller("di_n5")
+    x0, e0 = common.sample_params(zon, 2, 33, seed=9)
+    host = ctl.solve_batch(x0, e0)
+    dev = torch.device("cuda", 0)
+    tx, te = torch.from_numpy(x0).to(dev), torch.from_numpy(e0).to(dev)
+    v = torch.empty((33, 5, 1), dtype=torch.float64, device=dev); xb = torch.empty((33, 6, 2), dtype=torch.float64, device=dev)
+    cost = torch.empty(33, dtype=torch.float64, device=dev); st = torch.empty(33, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctl._native.solve_batch_ptr(33, tx.data_ptr(), te.data_ptr(), v.data_ptr(), xb.data_ptr(), cost.data_ptr(), st.data_ptr())
+    ctl._native.sync()
+    assert np.array_equal(v.cpu().numpy(), host["v"]) and np.array_equal(cost.cpu().numpy(), host["cost"])
+    assert (st.cpu().numpy() == 0).all()

@@ -1,0 +1,180 @@
+"""CPU-side checks of the product's host logic: cplite capture, builder structure, ABI surface, C oracle, sharding."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import common
+from tzddpc_amd import cplite as cp
+
+
+def _vars(N=3, n=2, m=1):
+    nsym = N * m + N * m + n
+    Cv = np.zeros((N * m, nsym)); Cv[:, :N * m] = np.eye(N * m)
+    x = cp.Affine(np.eye(nsym)[:N * n] if N * n <= nsym else np.zeros((N * n, nsym)), np.zeros(N * n), (N, n))
+    return cp.Affine(Cv, np.zeros(N * m), (N, m)), x, nsym
+
+
+def test_cplite_atoms_and_values():
+    u, x, nsym = _vars()
+    rng = np.random.default_rng(0)
+    xi = rng.standard_normal(nsym)
+    cost = 0
+    for i in range(u.shape[0]):
+        cost += cp.norm(x[i, :], p=2) ** 2 + 1e-2 * cp.norm(u[i], p=1)
+    cost = cp.as_convex(cost, nsym)
+    X = x.value_at(xi); U = u.value_at(xi)
+    assert np.isclose(cost.value_at(xi), (X ** 2).sum() + 1e-2 * np.abs(U).sum())
+    c2 = cp.as_convex(3.0 * cp.norm(x[1, 0] - 1, p=2) + cp.norm(x[0], "inf") + cp.sum_squares(2 * x[2] - 1), nsym)
+    assert np.isclose(c2.value_at(xi), 3 * abs(X[1, 0] - 1) + np.abs(X[0]).max() + ((2 * X[2] - 1) ** 2).sum())
+    Q = np.array([[2.0, 0.5], [0.5, 1.0]])
+    assert np.isclose(cp.as_convex(cp.quad_form(x[0], Q), nsym).value_at(xi), X[0] @ Q @ X[0])
+    con = x[:, 1] <= 10
+    assert con.kind == "<=" and con.expr.shape == (3,)
+    np.testing.assert_allclose((x @ np.array([[1.0], [2.0]])).value_at(xi)[:, 0], X @ [1.0, 2.0])
+    np.testing.assert_allclose((np.array([[1.0, 2.0, 3.0]]) @ x).value_at(xi), np.array([[1.0, 2.0, 3.0]]) @ X)
+
+
+def test_cplite_rejects_what_the_qp_path_cannot_express():
+    u, x, nsym = _vars()
+    with pytest.raises(cp.CpliteError):
+        cp.as_convex(cp.norm(x[0, :], p=2), nsym)              # second-order cone
+    with pytest.raises(cp.CpliteError):
+        x[0, 0] * x[0, 1]
+    with pytest.raises(cp.CpliteError):
+        -1.0 * cp.norm(u[0], 1)
+    with pytest.raises(cp.CpliteError):
+        cp.norm(x[0], 3)
+
+
+def test_builder_structure_and_reference_quirks():
+    ctl, qp, (A, B, zon) = common.identified_qp("di_n5")
+    N, n, m = 5, 2, 1
+    assert qp.ntheta == 2 * n + N * (2 * n + m)
+    assert list(qp.tube.power) == [0, 1, 2, 3, 4]               # full problem: term1[k-1] = M_K^k <e0>
+    # k = 0 state rows are parameter-only (xbar0 + e0 in X, reference :191-195 at k = 0)
+    assert len(qp.f0) >= 2 * n
+    # free u (reference :160,222): its L1 term vanishes, so no epigraph variable for it exists
+    assert not any(v.startswith("s[") for v in qp.var_names)
+    # v[N-1] and xbar[N] are unconstrained by the loss (non-unique): P has no curvature on the last input
+    assert np.allclose(qp.P[N * m - 1], 0.0)
+    ctl2, qp2, _ = common.identified_qp("di_n20_k1")
+    assert list(qp2.tube.power[:5]) == [0, 1, 2, 3, 3] and qp2.tube.pmax == 3     # simplified: powers saturate at k0 + 2
+    assert sum(v.startswith("s[") for v in qp2.var_names) == 20                  # loss(v, xbar[1:]): |v_i| is real (:336)
+    with pytest.raises(Exception):
+        from tzddpc_amd.builder import build_parametric_qp
+        build_parametric_qp(A, B, ctl.MdataK.center, ctl.MdataK.single_entry_magnitudes(), ctl.Mdelta.single_entry_magnitudes(),
+                            ctl.theta.K, zon.W.center, zon.W.generators, [-1, -1], [1, 1], [-1], [1], 3, lambda u, x: None, None)
+
+
+def test_structure_error_for_dense_generators():
+    from tzddpc_amd import TZDDPC
+    from tzddpc_amd.builder import StructureError
+    from tzddpc_amd.harness import generate_trajectories, system
+    A, B, zon, T = system("di_cc")
+    ctl = TZDDPC.__new__(TZDDPC); ctl.device = 0; ctl._native = None; ctl.qp = None
+    ctl.update_identification_data(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, np.random.default_rng(3)))
+    ctl.build_zonotopes_theta(zon)
+    ctl.MdataK.generators[0][0, 1] = 0.3                        # a generator with two non-zeros: literal path needed
+    with pytest.raises(StructureError):
+        ctl.build_problem(3, common.loss_di, common.nocons)
+
+
+def test_header_symbols_are_exported(built):
+    from tzddpc_amd import native
+    hdr = open(os.path.join(common.__file__.rsplit("/tests/", 1)[0], "include", "tzddpc.h")).read()
+    names = set(re.findall(r"^(?:int|const char\*)\s+(tz_\w+)\s*\(", hdr, flags=re.M))
+    assert names == set(native.EXPORTED_SYMBOLS), names ^ set(native.EXPORTED_SYMBOLS)
+    L = native.lib()
+    for nm in names:
+        assert hasattr(L, nm)
+    assert L.tz_abi_version() == native.TZ_ABI_VERSION
+
+
+def test_product_fails_loudly_without_gpu(built):
+    """No CPU fallback: on a box without a HIP device problem creation raises (skipped where a GPU exists)."""
+    from tzddpc_amd import native
+    try:
+        ndev = native.device_count()
+    except native.NativeError:
+        ndev = 0
+    if ndev > 0:
+        pytest.skip("GPU present")
+    from tzddpc_amd import TZDDPC
+    from tzddpc_amd.harness import generate_trajectories, system
+    A, B, zon, T = system("di_cc")
+    ctl = TZDDPC(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, np.random.default_rng(3)))
+    ctl.build_zonotopes_theta(zon)
+    with pytest.raises(native.NativeError):
+        ctl.build_problem(3, common.loss_di, common.nocons)
+    with pytest.raises(Exception):
+        ctl.solve(np.zeros(2), np.zeros(2))
+
+
+@pytest.mark.parametrize("case", ["di_n5", "pulley_n10"])
+def test_c_oracle_matches_numpy_oracle(built, case):
+    from oracle.c_oracle import COracle
+    ctl, qp, (A, B, zon) = common.identified_qp(case)
+    x0, e0 = common.sample_params(zon, qp.n, 4)
+    out = COracle(qp).solve_batch(x0, e0, threads=2, want_active=True)
+    assert (out["status"] == 0).all()
+    for b in range(4):
+        ref = common.oracle_solution(qp, x0[b], e0[b])
+        assert abs(out["cost"][b] - ref["cost"]) <= 1e-8 * (1 + abs(ref["cost"]))
+        np.testing.assert_allclose(out["v"][b, 0], ref["v"][0], atol=1e-6)
+        np.testing.assert_allclose(out["xbar"][b, 1], ref["xbar"][1], atol=1e-6)
+
+
+def test_c_oracle_flags_parameter_infeasibility(built):
+    from oracle.c_oracle import COracle
+    ctl, qp, (A, B, zon) = common.identified_qp("di_n5")
+    x0 = np.array([[50.0, 0.0]]); e0 = np.zeros((1, 2))          # xbar0 far outside X: reference raises 'Problem is unbounded'
+    out = COracle(qp).solve_batch(x0, e0)
+    assert out["status"][0] == 3 and np.isinf(out["cost"][0])
+
+
+def test_shard_ranges_partition_the_batch():
+    from tzddpc_amd.dist import shard_range, vertex_noise
+    for total, ws in [(1024, 1), (1024, 8), (1000, 3), (7, 8)]:
+        parts = [shard_range(total, ws, r) for r in range(ws)]
+        assert parts[0][0] == 0 and parts[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
+    Wv = np.array([[1.0, 0.0], [-1.0, 0.0], [0.0, 1.0], [0.0, -1.0]])
+    full = vertex_noise(Wv, 0, 6, 5)
+    np.testing.assert_array_equal(full[2:5], vertex_noise(Wv, 2, 3, 5))     # noise does not depend on the sharding
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from tzddpc_amd.dist import shard_range, gather_results
+rank = int(os.environ["RANK"]); ws = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=rank, world_size=ws)
+total = 11
+lo, hi = shard_range(total, ws, rank)
+full = torch.arange(total * 3, dtype=torch.float64).reshape(total, 3)
+got = gather_results(full[lo:hi].clone(), total)
+assert torch.equal(got, full), (rank, got)
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_gather_results_world_size_2_gloo(tmp_path):
+    """N > 1 path on CPU: two ranks each own a shard, one all-gather rebuilds the per-trajectory table in order."""
+    root = common.__file__.rsplit("/tests/", 1)[0]
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script), root, port], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()

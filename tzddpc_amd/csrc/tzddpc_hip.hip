@@ -76,7 +76,7 @@ struct tz_problem {
   DevBuf<IpmItem> items;
   DevCsr q, h, par;
   size_t lds_bytes = 0;
-  int64_t mfma_gram = 0, mfma_chol = 0;
+  int64_t mfma_gram = 0, mfma_chol = 0, mfma_issued = 0;
   // workspace (capacity Bcap)
   int Bcap = 0;
   DevBuf<double> theta, tube_ws, qv, hv, x, s, lam, v, xbar, cost, in_x0, in_e0;
@@ -294,12 +294,19 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   std::vector<int> item_ptr(TZ_NWAVES + 1, 0);
   p->mfma_gram = 0;
   for (int w = 0; w < TZ_NWAVES; ++w) {
-    for (int idx : per_wave[w]) { items_sorted.push_back(items[idx]); p->mfma_gram += (int64_t)items[idx].klen * 8; }
+    for (int idx : per_wave[w]) {
+      const IpmItem& it = items[idx];
+      items_sorted.push_back(it);
+      const int validI = std::min(4, Tz - it.I0);
+      p->mfma_gram += (int64_t)it.klen * validI * it.nq;
+      p->mfma_issued += (int64_t)it.klen * 8;
+    }
     item_ptr[w + 1] = (int)items_sorted.size();
   }
   p->mfma_chol = 0;
   for (int pp = 0; pp < Tz; ++pp)
     for (int I = pp + 1; I < Tz; ++I) p->mfma_chol += (I >> 2) - ((pp + 1) >> 2) + 1;
+  p->mfma_issued += p->mfma_chol;
 
   TZ_HIP(p->P.upload(P)); TZ_HIP(p->G.upload(G)); TZ_HIP(p->Gt.upload(Gt)); TZ_HIP(p->Gp.upload(Gp));
   if (klist.empty()) klist.push_back(0);
@@ -466,10 +473,12 @@ int tz_timing_get(tz_problem* p, int kernel, double* total_ms, int64_t* launches
   return TZ_OK;
 }
 
-int tz_ipm_plan_info(tz_problem* p, int64_t* mfma_gram_per_iter, int64_t* mfma_chol_per_iter, int64_t* lds_bytes, int64_t* patch_bytes) {
+int tz_ipm_plan_info(tz_problem* p, int64_t* mfma_gram_per_iter, int64_t* mfma_chol_per_iter, int64_t* mfma_issued_per_iter,
+                     int64_t* lds_bytes, int64_t* patch_bytes) {
   if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
   if (mfma_gram_per_iter) *mfma_gram_per_iter = p->mfma_gram;
   if (mfma_chol_per_iter) *mfma_chol_per_iter = p->mfma_chol;
+  if (mfma_issued_per_iter) *mfma_issued_per_iter = p->mfma_issued;
   if (lds_bytes) *lds_bytes = (int64_t)p->lds_bytes;
   if (patch_bytes) *patch_bytes = (int64_t)p->Gp.n * 8;
   return TZ_OK;

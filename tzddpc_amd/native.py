@@ -76,7 +76,7 @@ def lib():
     L.tz_mpc_step.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.tz_timing_enable.argtypes = [vp, C.c_int]
     L.tz_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    L.tz_ipm_plan_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.tz_ipm_plan_info.argtypes = [vp] + [C.POINTER(C.c_int64)] * 5
     L.tz_debug_fetch.argtypes = [vp, C.c_int32, C.c_int, vp, C.c_int32]
     for name in ("tz_device_count", "tz_problem_create", "tz_problem_destroy", "tz_problem_set_stream", "tz_problem_sync",
                  "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_timing_enable", "tz_timing_get",
@@ -230,9 +230,10 @@ class Problem:
         return ms.value, cnt.value
 
     def plan_info(self):
-        a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        check(lib().tz_ipm_plan_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "tz_ipm_plan_info")
-        return dict(mfma_gram_per_iter=a.value, mfma_chol_per_iter=b.value, lds_bytes=c.value, patch_bytes=d.value)
+        a, b, i, c, d = (C.c_int64(0) for _ in range(5))
+        check(lib().tz_ipm_plan_info(self._h, C.byref(a), C.byref(b), C.byref(i), C.byref(c), C.byref(d)), "tz_ipm_plan_info")
+        return dict(mfma_gram_per_iter=a.value, mfma_chol_per_iter=b.value, mfma_issued_per_iter=i.value,
+                    lds_bytes=c.value, patch_bytes=d.value)
 
     def debug_fetch(self, b: int, what: int) -> np.ndarray:
         cap = max(self.nz, self.mi, self.ntheta)
