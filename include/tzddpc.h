@@ -92,6 +92,8 @@ typedef struct tz_problem_desc {
   /* multipliers per row of the two-sided problem the host built (for the active-set report) */
   int32_t nc_rows;          /* rows of that problem */
   const int32_t* row_of;    /* mi: which of those rows an inequality row belongs to */
+  const double* act_scale;  /* mi: c / E_r^2; row r is reported active iff s_r * act_scale_r < lambda_r, i.e. iff the
+                             * UNSCALED slack is smaller than the UNSCALED multiplier (strict-complementarity partition) */
   /* tube constants (reference :119-128 after reduce(1); :175, :181) */
   const double* CK;         /* n x n  center of MdataK = Ahat + Bhat K */
   const double* DK;         /* n x n  sum_i |G_i| of MdataK's single-entry generators */

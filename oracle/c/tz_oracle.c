@@ -270,7 +270,7 @@ static void solve_one(const tzo_desc* d, const setup_t* S, const double* xbar0, 
   }
   if (active) {
     memset(active, 0, (size_t)d->nc);
-    if (feas) for (int k = 0; k < mi; ++k) if (s[k] < lam[k]) active[S->row[k]] = 1;
+    if (feas) for (int k = 0; k < mi; ++k) if (s[k] * S->c / (S->E[k] * S->E[k]) < lam[k]) active[S->row[k]] = 1;   /* unscaled slack < unscaled multiplier */
   }
 }
 

@@ -1,0 +1,514 @@
+// Batched Mehrotra predictor-corrector interior point kernel: one 256-thread workgroup per trajectory.
+//
+//   min 1/2 x'Px + q'x   s.t.  G x + s = h,  s >= 0          (scaled, one-sided; lambda >= 0)
+//
+// per iteration:  H = P + G' diag(lambda/s) G + reg I   (v_mfma_f64_4x4x4, block-sparse plan, operands prefetched 3 deep)
+//                 H = L L'                               (tile-4 blocked Cholesky in LDS, trailing updates by MFMA)
+//                 two solves (predictor, corrector), five G / G' mat-vecs, step-length reductions.
+// Row quantities (s, lambda, ds, dlambda, h, Gx, ...) live in registers of the thread that owns the row
+// (MAXR rows per thread); LDS holds H (lower triangle, quads in MFMA lane order), the nz-vectors and one
+// row-vector staging buffer, so that four workgroups fit on a CU for the benchmark sizes.
+#pragma once
+
+struct IpmItem { int I0, q0, nq, kptr, klen; };
+
+struct IpmParams {
+  int B, nz, mi, nzp, mip, Tz, Kc, nquads, nklist, nP;   // nP: rows of P beyond which P is zero
+  const double* P;       // nzp x nzp
+  const double* G;       // mip x nzp   (row-major, zero padded)
+  const double* Gt;      // nzp x mip   (transpose)
+  const double* Gp;      // (Kc+1) x Tz x 16 patches: Gp[(kc*Tz + J)*16 + 4k + j] = G[4kc+k][4J+j]; row Kc is all zero
+  const IpmItem* items;  // Gram work items, grouped per wave
+  const int* item_ptr;   // TZ_NWAVES + 1
+  const int* klist;
+  const double* q; const double* h;
+  const int* prestatus;
+  double* x; double* s; double* lam;
+  int* status; int* iters;
+  int max_iter; double tol, reg, step_frac;
+  unsigned long long* prof;   // TZ_PROF=1: per-phase cycle sums of workgroup 0 (diagnostic; no output depends on it)
+};
+
+enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_COUNT = 8 };
+
+__device__ inline int tz_qprefix(int I) {   // number of quads in tile rows < I (row I has (I>>2)+1 quads)
+  int a = I >> 2, b = I & 3;
+  return (a + 1) * (2 * a + b);
+}
+__device__ inline int tz_hidx(int r, int c) {   // LDS index of H(r, c), r >= c (tile-row major, quads in lane order)
+  int I = r >> 2, J = c >> 2;
+  return (tz_qprefix(I) + (J >> 2)) * 64 + 16 * (r & 3) + 4 * (J & 3) + (c & 3);
+}
+
+enum { RED_SUM = 0, RED_MAX = 1, RED_MIN = 2 };
+
+template <int OP>
+__device__ inline double tz_wave_reduce(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double o = __shfl_down(v, off, 64);
+    if (OP == RED_SUM) v += o;
+    else if (OP == RED_MAX) v = fmax(v, o);
+    else v = fmin(v, o);
+  }
+  return v;
+}
+
+// three simultaneous block reductions (ops fixed at compile time); result broadcast to all threads.
+template <int OP0, int OP1, int OP2>
+__device__ inline void tz_block_reduce3(double& a, double& b, double& c, double* red) {
+  a = tz_wave_reduce<OP0>(a); b = tz_wave_reduce<OP1>(b); c = tz_wave_reduce<OP2>(c);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();                       // protect red[] from the previous use
+  if (lane == 0) { red[w] = a; red[4 + w] = b; red[8 + w] = c; }
+  __syncthreads();
+  double ra = red[0], rb = red[4], rc = red[8];
+#pragma unroll
+  for (int i = 1; i < TZ_NWAVES; ++i) {
+    double va = red[i], vb = red[4 + i], vc = red[8 + i];
+    ra = (OP0 == RED_SUM) ? ra + va : (OP0 == RED_MAX ? fmax(ra, va) : fmin(ra, va));
+    rb = (OP1 == RED_SUM) ? rb + vb : (OP1 == RED_MAX ? fmax(rb, vb) : fmin(rb, vb));
+    rc = (OP2 == RED_SUM) ? rc + vc : (OP2 == RED_MAX ? fmax(rc, vc) : fmin(rc, vc));
+  }
+  a = ra; b = rb; c = rc;
+}
+
+// out[k] = (G in)_r for the rows r = t + 256 k this thread owns; `in` (nz entries) in LDS.
+template <int MAXR>
+__device__ inline void tz_gemv_G(const IpmParams& p, const double* in, double (&out)[MAXR]) {
+#pragma unroll
+  for (int k = 0; k < MAXR; ++k) {
+    const int r = threadIdx.x + TZ_THREADS * k;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (r < p.mi) {
+      const double* g = p.Gt + r;
+      const size_t ld = (size_t)p.mip;
+      int c = 0;
+      for (; c + 7 < p.nz; c += 8) {
+        const double g0 = g[c * ld], g1 = g[(c + 1) * ld], g2 = g[(c + 2) * ld], g3 = g[(c + 3) * ld];
+        const double g4 = g[(c + 4) * ld], g5 = g[(c + 5) * ld], g6 = g[(c + 6) * ld], g7 = g[(c + 7) * ld];
+        a0 += g0 * in[c]; a1 += g1 * in[c + 1]; a2 += g2 * in[c + 2]; a3 += g3 * in[c + 3];
+        a0 += g4 * in[c + 4]; a1 += g5 * in[c + 5]; a2 += g6 * in[c + 6]; a3 += g7 * in[c + 7];
+      }
+      for (; c < p.nz; ++c) a0 += g[c * ld] * in[c];
+    }
+    out[k] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+// part[w][c] = sum over the rows r = w, w+4, ... of M[r][c] in[r]  (row-major M, rows x nzp; `in` in LDS).
+// NCG = ceil(nzp / 64) column groups per lane.  The four per-wave partials are combined by tz_gemvT_get.
+template <int NCG>
+__device__ inline void tz_gemvT_partial(const double* M, int rows, int nzp, const double* in, double* part) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int UR = (NCG <= 2) ? 8 : 4;
+  double acc[NCG];
+#pragma unroll
+  for (int g = 0; g < NCG; ++g) acc[g] = 0.0;
+  int r = w;
+  for (; r + (UR - 1) * TZ_NWAVES < rows; r += UR * TZ_NWAVES) {
+    double v[UR], m[UR][NCG];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      v[u] = in[r + u * TZ_NWAVES];
+      const double* row = M + (size_t)(r + u * TZ_NWAVES) * nzp;
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) { const int c = min(lane + 64 * g, nzp - 1); m[u][g] = row[c]; }   // clamped: columns >= nzp are never stored
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u)
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) acc[g] += m[u][g] * v[u];
+  }
+  for (; r < rows; r += TZ_NWAVES) {
+    const double v = in[r];
+    const double* row = M + (size_t)r * nzp;
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) { const int c = min(lane + 64 * g, nzp - 1); acc[g] += row[c] * v; }
+  }
+#pragma unroll
+  for (int g = 0; g < NCG; ++g) { const int c = lane + 64 * g; if (c < nzp) part[w * nzp + c] = acc[g]; }
+}
+__device__ inline double tz_gemvT_get(const double* part, int nzp, int c) {
+  return (part[c] + part[nzp + c]) + (part[2 * nzp + c] + part[3 * nzp + c]);
+}
+
+// Gram matrix  H = P + G' diag(w) G + reg I  into LDS quads, by v_mfma_f64_4x4x4 (blk = 4 column tiles).
+// wv: LDS, mip + 4 entries, entries >= mi are zero.  kl: k-lists in LDS.
+struct TzStage { double a[4]; double b[2]; double w; };
+
+__device__ inline void tz_form_H(const IpmParams& p, double* Hq, const double* wv, const int* kl) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
+  const int Tz = p.Tz;
+  const size_t rowstride = (size_t)Tz * 16;
+  const double* gbase = p.Gp + 4 * k + ij;
+  for (int it = p.item_ptr[wave]; it < p.item_ptr[wave + 1]; ++it) {
+    const IpmItem item = p.items[it];
+    const int* kli = kl + item.kptr;
+    const int klen = item.klen;
+    double acc[4][2];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) { acc[ii][0] = 0.0; acc[ii][1] = 0.0; }
+    // operand offsets inside a patch row; invalid tiles point at tile 0 of the all-zero patch row (kc = Kc) instead of
+    // being skipped, so that every load is unconditional (conditional loads end in s_waitcnt vmcnt(0) and kill the prefetch)
+    int aoff[4], boff[2]; bool aok[4], bok[2];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) { aok[ii] = item.I0 + ii < Tz; aoff[ii] = aok[ii] ? (item.I0 + ii) * 16 : 0; }
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) { const int J = 4 * (item.q0 + nn) + blk; bok[nn] = (nn < item.nq) && (J < Tz); boff[nn] = bok[nn] ? J * 16 : 0; }
+    const double* zrow = gbase + (size_t)p.Kc * rowstride;
+    auto load = [&](int kk, TzStage& st) {
+      const int kc = kli[kk];                                // lists are padded with Kc (zero patch row) past their end
+      st.w = wv[4 * kc + k];
+      const double* prow = gbase + (size_t)kc * rowstride;
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) { const double* pa = aok[ii] ? prow + aoff[ii] : zrow; st.a[ii] = *pa; }
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn) { const double* pb = bok[nn] ? prow + boff[nn] : zrow; st.b[nn] = *pb; }
+    };
+    auto fma8 = [&](const TzStage& st) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const double a = st.a[ii] * st.w;
+        acc[ii][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, st.b[0], acc[ii][0], 0, 0, 0);
+        acc[ii][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, st.b[1], acc[ii][1], 0, 0, 0);
+      }
+    };
+    TzStage s0, s1, s2, s3;
+    load(0, s0); load(1, s1); load(2, s2);
+    for (int kk = 0; kk < klen; kk += 4) {
+      load(kk + 3, s3); fma8(s0);
+      load(kk + 4, s0); fma8(s1);
+      load(kk + 5, s1); fma8(s2);
+      load(kk + 6, s2); fma8(s3);
+    }
+    // D lane (i = lane>>4, blk, j = lane&3) = H(4I + i, 4(4q + blk) + j)
+    const int i = lane >> 4, j = lane & 3;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int I = item.I0 + ii;
+      if (I >= Tz) continue;
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn) {
+        const int q = item.q0 + nn;
+        if (nn >= item.nq || q > (I >> 2)) continue;
+        const int r = 4 * I + i, c = 4 * (4 * q + blk) + j;
+        double v = acc[ii][nn];
+        if (c < p.nzp) v += p.P[(size_t)r * p.nzp + c];
+        if (r == c) v = (r < p.nz) ? v + p.reg : 1.0;
+        Hq[(tz_qprefix(I) + q) * 64 + lane] = v;
+      }
+    }
+  }
+}
+
+// sqrt(d) and 1/sqrt(d) from v_rsq_f64 + two coupled Newton steps (deterministic, ~1 ulp; no f64 divide / sqrt sequences)
+__device__ inline void tz_sqrt_rsqrt(double d, double& sq, double& rs) {
+  double y = __builtin_amdgcn_rsq(d);
+  double g = d * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  const double e = __builtin_fma(-g, g, d);
+  g = __builtin_fma(e, h, g);
+  double inv = h + h;
+  const double e2 = __builtin_fma(-g, inv, 1.0);
+  inv = __builtin_fma(e2, inv, inv);
+  sq = g; rs = inv;
+}
+
+// In-place blocked Cholesky (tile 4) of the quad-stored matrix.  Off-diagonal tiles of Hq become L; the diagonal tiles are
+// not written back (nothing reads them again): dinv[p] receives the inverse of the diagonal tile's factor.
+__device__ inline bool tz_cholesky(const IpmParams& p, double* Hq, double* dinv, int* flag) {
+  const int Tz = p.Tz;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
+  for (int pp = 0; pp < Tz; ++pp) {
+    const int dbase = (tz_qprefix(pp) + (pp >> 2)) * 64 + 4 * (pp & 3);
+    const double a00 = Hq[dbase], a10 = Hq[dbase + 16], a11 = Hq[dbase + 17];
+    const double a20 = Hq[dbase + 32], a21 = Hq[dbase + 33], a22 = Hq[dbase + 34];
+    const double a30 = Hq[dbase + 48], a31 = Hq[dbase + 49], a32 = Hq[dbase + 50], a33 = Hq[dbase + 51];
+    bool ok = true;
+    double l00, i00, l11, i11, l22, i22, l33, i33;
+    ok = ok && (a00 > 0.0);
+    tz_sqrt_rsqrt(fmax(a00, 1e-300), l00, i00);
+    const double l10 = a10 * i00, l20 = a20 * i00, l30 = a30 * i00;
+    const double d1 = a11 - l10 * l10; ok = ok && (d1 > 0.0);
+    tz_sqrt_rsqrt(fmax(d1, 1e-300), l11, i11);
+    const double l21 = (a21 - l20 * l10) * i11, l31 = (a31 - l30 * l10) * i11;
+    const double d2 = a22 - l20 * l20 - l21 * l21; ok = ok && (d2 > 0.0);
+    tz_sqrt_rsqrt(fmax(d2, 1e-300), l22, i22);
+    const double l32 = (a32 - l30 * l20 - l31 * l21) * i22;
+    const double d3 = a33 - l30 * l30 - l31 * l31 - l32 * l32; ok = ok && (d3 > 0.0);
+    tz_sqrt_rsqrt(fmax(d3, 1e-300), l33, i33);
+    (void)l33;
+    if (threadIdx.x == 0) {
+      if (!ok) *flag = 1;
+      const double m10 = -l10 * i00 * i11;
+      const double m21 = -l21 * i11 * i22;
+      const double m32 = -l32 * i22 * i33;
+      const double m20 = -(l20 * i00 + l21 * m10) * i22;
+      const double m31 = -(l31 * i11 + l32 * m21) * i33;
+      const double m30 = -(l30 * i00 + l31 * m10 + l32 * m20) * i33;
+      double* di = dinv + pp * 16;
+      di[0] = i00; di[1] = 0; di[2] = 0; di[3] = 0;
+      di[4] = m10; di[5] = i11; di[6] = 0; di[7] = 0;
+      di[8] = m20; di[9] = m21; di[10] = i22; di[11] = 0;
+      di[12] = m30; di[13] = m31; di[14] = m32; di[15] = i33;
+    }
+    // panel: rows of tiles (I, pp), I > pp:  x L_pp' = a
+    for (int t = threadIdx.x; t < 4 * (Tz - pp - 1); t += TZ_THREADS) {
+      const int I = pp + 1 + (t >> 2), i = t & 3;
+      const int base = (tz_qprefix(I) + (pp >> 2)) * 64 + 16 * i + 4 * (pp & 3);
+      const double b0 = Hq[base], b1 = Hq[base + 1], b2 = Hq[base + 2], b3 = Hq[base + 3];
+      const double x0 = b0 * i00;
+      const double x1 = (b1 - x0 * l10) * i11;
+      const double x2 = (b2 - x0 * l20 - x1 * l21) * i22;
+      const double x3 = (b3 - x0 * l30 - x1 * l31 - x2 * l32) * i33;
+      Hq[base] = x0; Hq[base + 1] = x1; Hq[base + 2] = x2; Hq[base + 3] = x3;
+    }
+    __syncthreads();
+    // trailing update  H(I, J) -= L(I, pp) L(J, pp)'  for pp < J <= I.  Wave w owns the tile rows I = pp+1+w, pp+5+w, ...;
+    // per row one MFMA per quad, the row's quads issued back to back (independent accumulators).
+    {
+      const int poff = 4 * (pp & 3) + k, pq = pp >> 2, q0 = (pp + 1) >> 2;
+      for (int I = pp + 1 + wave; I < Tz; I += TZ_NWAVES) {
+        const int qI = tz_qprefix(I);
+        const double a = -Hq[(qI + pq) * 64 + 16 * ij + poff];             // -L(4I+i, 4pp+k), i = ij
+        const int nq = (I >> 2) - q0 + 1;
+        for (int qb = 0; qb < nq; qb += 4) {
+          double bb[4], c[4]; bool vd[4]; int ci[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int q = q0 + qb + u;
+            const int J = 4 * q + blk;
+            vd[u] = (qb + u < nq) && (J > pp) && (J <= I);
+            ci[u] = (qI + q) * 64 + lane;
+            const int Jc = vd[u] ? J : I;                                            // safe tile for masked lanes
+            const double bl = Hq[(tz_qprefix(Jc) + pq) * 64 + 16 * ij + poff];       // L(4J+j, 4pp+k), j = ij
+            bb[u] = vd[u] ? bl : 0.0;
+            ci[u] = vd[u] ? ci[u] : (qI + pq) * 64 + lane;
+            c[u] = Hq[ci[u]];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) c[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb[u], c[u], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (vd[u]) Hq[ci[u]] = c[u];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  return *flag == 0;
+}
+
+// Solve (L L') out = rhs.  rhs is destroyed; tmp receives the forward solution.  All in LDS, nzp entries.
+__device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const double* dinv,
+                                     double* rhs, double* tmp, double* out) {
+  const int Tz = p.Tz, nzp = p.nzp;
+  const int t = threadIdx.x;
+  for (int I = 0; I < Tz; ++I) {                 // forward: L y = rhs
+    const double r0 = rhs[4 * I], r1 = rhs[4 * I + 1], r2 = rhs[4 * I + 2], r3 = rhs[4 * I + 3];
+    const double* di = dinv + I * 16;
+    const double y0 = di[0] * r0;
+    const double y1 = di[4] * r0 + di[5] * r1;
+    const double y2 = di[8] * r0 + di[9] * r1 + di[10] * r2;
+    const double y3 = di[12] * r0 + di[13] * r1 + di[14] * r2 + di[15] * r3;
+    if (t == 0) { tmp[4 * I] = y0; tmp[4 * I + 1] = y1; tmp[4 * I + 2] = y2; tmp[4 * I + 3] = y3; }
+    for (int r = 4 * (I + 1) + t; r < nzp; r += TZ_THREADS) {
+      const int base = tz_hidx(r, 4 * I);
+      rhs[r] -= Hq[base] * y0 + Hq[base + 1] * y1 + Hq[base + 2] * y2 + Hq[base + 3] * y3;
+    }
+    __syncthreads();
+  }
+  for (int I = Tz - 1; I >= 0; --I) {            // backward: L' out = tmp
+    const double y0 = tmp[4 * I], y1 = tmp[4 * I + 1], y2 = tmp[4 * I + 2], y3 = tmp[4 * I + 3];
+    const double* di = dinv + I * 16;            // x = M' y  (M lower)
+    const double x3 = di[15] * y3;
+    const double x2 = di[10] * y2 + di[14] * y3;
+    const double x1 = di[5] * y1 + di[9] * y2 + di[13] * y3;
+    const double x0 = di[0] * y0 + di[4] * y1 + di[8] * y2 + di[12] * y3;
+    if (t == 0) { out[4 * I] = x0; out[4 * I + 1] = x1; out[4 * I + 2] = x2; out[4 * I + 3] = x3; }
+    for (int c = t; c < 4 * I; c += TZ_THREADS) {
+      const int base = (tz_qprefix(I) + (c >> 4)) * 64 + 4 * ((c >> 2) & 3) + (c & 3);
+      tmp[c] -= Hq[base] * x0 + Hq[base + 16] * x1 + Hq[base + 32] * x2 + Hq[base + 48] * x3;
+    }
+    __syncthreads();
+  }
+}
+
+// LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
+__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist) {
+  return (size_t)nquads * 64 + (size_t)Tz * 16 + 10 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2);
+}
+
+template <int MAXR, int NCG>
+__global__ __launch_bounds__(TZ_THREADS, 4) void tz_ipm_kernel(IpmParams p) {
+  const bool PROF = p.prof != nullptr && blockIdx.x == 0;
+  unsigned long long tprev = 0, tstart = 0;
+  unsigned long long acc_ph[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TZ_STAMP(ph) do { if (PROF) { unsigned long long _t = __builtin_amdgcn_s_memtime(); acc_ph[ph] += _t - tprev; tprev = _t; } } while (0)
+  if (PROF) { tprev = __builtin_amdgcn_s_memtime(); tstart = tprev; }
+  extern __shared__ double lds[];
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int nz = p.nz, mi = p.mi, nzp = p.nzp, mip = p.mip;
+  if (p.prestatus[b] != 0) {
+    if (t == 0) { p.status[b] = 3; p.iters[b] = 0; }
+    for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = 0.0;
+    for (int r = t; r < mi; r += TZ_THREADS) { p.s[(size_t)b * mi + r] = 1.0; p.lam[(size_t)b * mi + r] = 0.0; }
+    return;
+  }
+  double* Hq = lds;
+  double* dinv = Hq + (size_t)p.nquads * 64;
+  double* xv = dinv + p.Tz * 16;
+  double* dxv = xv + nzp;
+  double* rdv = dxv + nzp;
+  double* r1v = rdv + nzp;
+  double* qv = r1v + nzp;
+  double* tmpz = qv + nzp;
+  double* part = tmpz + nzp;              // 4 * nzp
+  double* vin = part + 4 * nzp;           // mip + 4 : staging of one row vector (w for the Gram, inputs of G' products)
+  double* red = vin + mip + 4;            // 16
+  int* flag = (int*)(red + 16);
+  int* kl = (int*)(red + 18);
+
+  // rows owned by this thread
+  double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR], w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR];
+#define TZ_ROWS(k, r) _Pragma("unroll") for (int k = 0; k < MAXR; ++k) if (const int r = t + TZ_THREADS * k; r < mi)
+
+  for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? p.q[(size_t)b * nz + c] : 0.0; xv[c] = 0.0; }
+  for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the start point
+  for (int i = t; i < p.nklist; i += TZ_THREADS) kl[i] = p.klist[i];
+#pragma unroll
+  for (int k = 0; k < MAXR; ++k) { s_[k] = 1.0; l_[k] = 0.0; h_[k] = 0.0; gx_[k] = 0.0; w_[k] = 0.0; rp_[k] = 0.0; ds_[k] = 0.0; dl_[k] = 0.0; g_[k] = 0.0; }
+  TZ_ROWS(k, r) { h_[k] = p.h[(size_t)b * mi + r]; l_[k] = 1.0; }
+  if (t == 0) *flag = 0;
+  __syncthreads();
+
+  // ---- start point: (P + G'G + reg) x = -q + G'h, then shift the slacks into the cone ----------
+  tz_form_H(p, Hq, vin, kl);
+  __syncthreads();
+  TZ_ROWS(k, r) vin[r] = h_[k];
+  __syncthreads();
+  tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
+  __syncthreads();
+  for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? tz_gemvT_get(part, nzp, c) - qv[c] : 0.0;
+  __syncthreads();
+  const bool okf = tz_cholesky(p, Hq, dinv, flag);
+  tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
+  tz_gemv_G<MAXR>(p, xv, gx_);
+  double scq = 0, sch = 0;
+  {
+    double rmin = 1e300;
+    TZ_ROWS(k, r) { rmin = fmin(rmin, h_[k] - gx_[k]); sch = fmax(sch, fabs(h_[k])); }
+    for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
+    tz_block_reduce3<RED_MIN, RED_MAX, RED_MAX>(rmin, scq, sch, red);
+    const double shift = (rmin <= 1e-8) ? fmax(0.0, 1.0 - rmin) : 0.0;
+    TZ_ROWS(k, r) s_[k] = h_[k] - gx_[k] + shift;
+  }
+  const double sc_d = 1.0 + scq, sc_p = 1.0 + sch;
+
+  int status = okf ? 1 : 2, it = 0;
+  for (it = 0; it < p.max_iter && status == 1; ++it) {
+    TZ_STAMP(PH_ELEM);
+    // residuals: rd = P x + q + G'lam ; rp = G x + s - h ; mu
+    TZ_ROWS(k, r) vin[r] = l_[k];
+    __syncthreads();
+    tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
+    __syncthreads();
+    for (int c = t; c < nzp; c += TZ_THREADS) rdv[c] = (c < nz) ? tz_gemvT_get(part, nzp, c) + qv[c] : 0.0;
+    __syncthreads();
+    tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
+    __syncthreads();
+    TZ_STAMP(PH_GEMVT);
+    double nrd = 0, nrp = 0, sl = 0;
+    for (int c = t; c < nz; c += TZ_THREADS) { const double v = rdv[c] + tz_gemvT_get(part, nzp, c); rdv[c] = v; nrd = fmax(nrd, fabs(v)); }
+    TZ_ROWS(k, r) { rp_[k] = gx_[k] + s_[k] - h_[k]; nrp = fmax(nrp, fabs(rp_[k])); sl += s_[k] * l_[k]; }
+    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(nrd, nrp, sl, red);
+    const double mu = sl / mi;
+    nrd /= sc_d; nrp /= sc_p;
+    if (nrd <= p.tol && nrp <= p.tol && mu <= p.tol) { status = 0; break; }
+    if (mu <= 1e-3 * p.tol) { status = (nrd <= 1e3 * p.tol && nrp <= 1e3 * p.tol) ? 0 : 3; break; }
+    if (!(mu == mu) || !(nrd == nrd) || mu > 1e200) { status = 2; break; }
+    // Newton matrix
+    TZ_ROWS(k, r) { w_[k] = l_[k] / s_[k]; vin[r] = w_[k]; }
+    __syncthreads();
+    TZ_STAMP(PH_ELEM);
+    tz_form_H(p, Hq, vin, kl);
+    __syncthreads();
+    TZ_STAMP(PH_FORM);
+    if (!tz_cholesky(p, Hq, dinv, flag)) { status = 2; break; }
+    TZ_STAMP(PH_CHOL);
+    // ---- predictor: rc = s*lam ------------------------------------------------------------------
+    TZ_ROWS(k, r) vin[r] = w_[k] * rp_[k] - l_[k];                    // (-rc + lam rp)/s
+    __syncthreads();
+    TZ_STAMP(PH_ELEM);
+    tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
+    __syncthreads();
+    for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? -rdv[c] - tz_gemvT_get(part, nzp, c) : 0.0;
+    __syncthreads();
+    TZ_STAMP(PH_GEMVT);
+    tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
+    TZ_STAMP(PH_SOLVE);
+    tz_gemv_G<MAXR>(p, dxv, g_);
+    TZ_STAMP(PH_GEMV);
+    double ap = 1.0, ad = 1.0, z0 = 0;
+    TZ_ROWS(k, r) {
+      const double ds = -rp_[k] - g_[k];
+      const double dl = -l_[k] - w_[k] * ds;
+      ds_[k] = ds; dl_[k] = dl;
+      if (ds < 0) ap = fmin(ap, -s_[k] / ds);
+      if (dl < 0) ad = fmin(ad, -l_[k] / dl);
+    }
+    tz_block_reduce3<RED_MIN, RED_MIN, RED_SUM>(ap, ad, z0, red);
+    double muaff = 0, z1 = 0, z2 = 0;
+    TZ_ROWS(k, r) muaff += (s_[k] + ap * ds_[k]) * (l_[k] + ad * dl_[k]);
+    tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(muaff, z1, z2, red);
+    muaff /= mi;
+    double sigma = muaff / mu; sigma = sigma * sigma * sigma;
+    // ---- corrector: rc = s*lam + dsa*dla - sigma mu -----------------------------------------------
+    TZ_ROWS(k, r) {
+      const double rc = s_[k] * l_[k] + ds_[k] * dl_[k] - sigma * mu;
+      vin[r] = (-rc + l_[k] * rp_[k]) / s_[k];
+      ds_[k] = rc;                                  // keep rc for the dl formula
+    }
+    __syncthreads();
+    TZ_STAMP(PH_ELEM);
+    tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
+    __syncthreads();
+    for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? -rdv[c] - tz_gemvT_get(part, nzp, c) : 0.0;
+    __syncthreads();
+    TZ_STAMP(PH_GEMVT);
+    tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
+    TZ_STAMP(PH_SOLVE);
+    tz_gemv_G<MAXR>(p, dxv, g_);
+    TZ_STAMP(PH_GEMV);
+    double as = 1e300, al = 1e300, z3 = 0;
+    TZ_ROWS(k, r) {
+      const double rc = ds_[k];
+      const double ds = -rp_[k] - g_[k];
+      const double dl = (-rc - l_[k] * ds) / s_[k];
+      ds_[k] = ds; dl_[k] = dl;
+      if (ds < 0) as = fmin(as, -s_[k] / ds);
+      if (dl < 0) al = fmin(al, -l_[k] / dl);
+    }
+    tz_block_reduce3<RED_MIN, RED_MIN, RED_SUM>(as, al, z3, red);
+    const double alpha = fmin(1.0, p.step_frac * fmin(as, al));
+    for (int c = t; c < nz; c += TZ_THREADS) xv[c] += alpha * dxv[c];
+    TZ_ROWS(k, r) { s_[k] += alpha * ds_[k]; l_[k] += alpha * dl_[k]; gx_[k] += alpha * g_[k]; }
+    __syncthreads();
+  }
+  for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = xv[c];
+  TZ_ROWS(k, r) { p.s[(size_t)b * mi + r] = s_[k]; p.lam[(size_t)b * mi + r] = l_[k]; }
+  if (t == 0) { p.status[b] = status; p.iters[b] = it; }
+  if (PROF && t == 0) {
+    TZ_STAMP(PH_ELEM);
+    acc_ph[PH_TOTAL] = tprev - tstart; acc_ph[7] = (unsigned long long)it;
+    for (int i = 0; i < PH_COUNT; ++i) p.prof[i] = acc_ph[i];
+  }
+#undef TZ_STAMP
+#undef TZ_ROWS
+}

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -62,16 +63,24 @@ struct DevCsr {
 
 enum { K_TUBE = 0, K_IPM = 1, K_FINISH = 2, K_PLANT = 3, K_COUNT = 4 };
 
+typedef void (*ipm_fn_t)(IpmParams);
+template <int R> ipm_fn_t ipm_pick_ncg(int ncg) {
+  switch (ncg) { case 1: return tz_ipm_kernel<R, 1>; case 2: return tz_ipm_kernel<R, 2>; case 3: return tz_ipm_kernel<R, 3>; default: return tz_ipm_kernel<R, 4>; }
+}
+ipm_fn_t ipm_kernel_for(int maxr, int ncg) {
+  switch (maxr) { case 1: return ipm_pick_ncg<1>(ncg); case 2: return ipm_pick_ncg<2>(ncg); case 3: return ipm_pick_ncg<3>(ncg); default: return ipm_pick_ncg<4>(ncg); }
+}
+
 }  // namespace
 
 struct tz_problem {
   int device = 0;
   int n = 0, m = 0, N = 0, nz = 0, mi = 0, ntheta = 0, npar = 0, nc_rows = 0, pmax = 0;
-  int nzp = 0, mip = 0, Tz = 0, Kc = 0, nquads = 0;
+  int nzp = 0, mip = 0, Tz = 0, Kc = 0, nquads = 0, nklist = 0, nP = 0;
   int max_iter = 40;
   double tol = 1e-10, reg = 1e-12, step_frac = 0.99, cost_scale = 1.0, r0 = 0.0;
   // constants
-  DevBuf<double> P, G, Gt, Gp, Dz, Phi, Gam, r1, R2, CK, DK, K, absCK, absKCK, par_lo, par_hi;
+  DevBuf<double> P, G, Gt, Gp, act_scale, Dz, Phi, Gam, r1, R2, CK, DK, K, absCK, absKCK, par_lo, par_hi;
   DevBuf<int> power, row_of, klist, item_ptr;
   DevBuf<IpmItem> items;
   DevCsr q, h, par;
@@ -93,6 +102,10 @@ struct tz_problem {
   double t_ms[K_COUNT] = {0, 0, 0, 0};
   int64_t t_count[K_COUNT] = {0, 0, 0, 0};
   int lastB = 0;
+  bool prof = false;
+  int maxr = 1, ncg = 1;
+  void (*ipm_fn)(IpmParams) = nullptr;
+  DevBuf<unsigned long long> prof_buf;
 };
 
 namespace {
@@ -178,12 +191,14 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
     ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
     ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
     ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac;
-    hipLaunchKernelGGL(tz_ipm_kernel, dim3(B), dim3(TZ_THREADS), p->lds_bytes, st, ip);
+    ip.prof = p->prof ? p->prof_buf.p : nullptr;
+    ip.nklist = p->nklist; ip.nP = p->nP;
+    hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, st, ip);
   }
   {
     Timer tm(p, K_FINISH);
     FinishParams fp{B, p->n, p->m, p->N, p->nz, p->mi, p->nzp, p->nc_rows, p->P.p, p->Dz.p, p->Phi.p, p->Gam.p,
-                    p->r1.p, p->R2.p, p->r0, p->cost_scale, p->row_of.p, d_xbar0, p->qv.p, p->x.p, p->s.p, p->lam.p,
+                    p->r1.p, p->R2.p, p->r0, p->cost_scale, p->row_of.p, p->act_scale.p, d_xbar0, p->qv.p, p->x.p, p->s.p, p->lam.p,
                     d_status, d_v, d_xbar, d_cost, d_active, cost_stride};
     hipLaunchKernelGGL(tz_finish_kernel, dim3(B), dim3(64), 0, st, fp);
   }
@@ -250,13 +265,15 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   for (int I = 0; I < Tz; ++I) p->nquads += (I >> 2) + 1;
 
   // padded dense copies
-  std::vector<double> P((size_t)nzp * nzp, 0.0), G((size_t)mip * nzp, 0.0), Gt((size_t)nzp * mip, 0.0), Gp((size_t)Kc * Tz * 16, 0.0);
+  std::vector<double> P((size_t)nzp * nzp, 0.0), G((size_t)mip * nzp, 0.0), Gt((size_t)nzp * mip, 0.0), Gp((size_t)(Kc + 1) * Tz * 16, 0.0);   // last patch row stays zero (prefetch padding)
   for (int r = 0; r < nz; ++r) for (int c = 0; c < nz; ++c) P[(size_t)r * nzp + c] = d->P[(size_t)r * nz + c];
   for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) {
     double v = d->G[(size_t)r * nz + c];
     G[(size_t)r * nzp + c] = v; Gt[(size_t)c * mip + r] = v;
     Gp[((size_t)(r >> 2) * Tz + (c >> 2)) * 16 + 4 * (r & 3) + (c & 3)] = v;
   }
+  p->nP = 0;
+  for (int r = 0; r < nz; ++r) for (int c = 0; c < nz; ++c) if (P[(size_t)r * nzp + c] != 0.0) p->nP = r + 1;
   // Gram plan: item = (block of 4 tile rows I0..I0+3, quads q0..q0+nq-1), k-list = chunks where the 16 columns are non-zero
   std::vector<int> klist;
   std::vector<IpmItem> items;
@@ -272,6 +289,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
       if (nzr) klist.push_back(kc);
     }
     const int klen = (int)klist.size() - kptr;
+    for (int z = 0; z < 8; ++z) klist.push_back(Kc);     // prefetch padding: the all-zero patch row
     const int Ilast = std::min(4 * IB + 3, Tz - 1);
     const int qmax = Ilast >> 2;          // quads 0..qmax exist for the last row of the block
     for (int q0 = 0; q0 <= qmax; q0 += 2) {
@@ -310,6 +328,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
 
   TZ_HIP(p->P.upload(P)); TZ_HIP(p->G.upload(G)); TZ_HIP(p->Gt.upload(Gt)); TZ_HIP(p->Gp.upload(Gp));
   if (klist.empty()) klist.push_back(0);
+  p->nklist = (int)klist.size();
   TZ_HIP(p->klist.upload(klist)); TZ_HIP(p->items.upload(items_sorted)); TZ_HIP(p->item_ptr.upload(item_ptr));
   TZ_HIP(p->q.upload(d->q)); TZ_HIP(p->h.upload(d->h)); TZ_HIP(p->par.upload(d->par));
   TZ_HIP(p->par_lo.upload(d->par_lo, (size_t)p->npar)); TZ_HIP(p->par_hi.upload(d->par_hi, (size_t)p->npar));
@@ -323,14 +342,17 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   TZ_HIP(p->absKCK.upload(d->absKCKpow, (size_t)std::max(d->pmax, 1) * d->m * d->n));
   TZ_HIP(p->power.upload(d->power, (size_t)d->N));
   TZ_HIP(p->row_of.upload(d->row_of, (size_t)mi));
+  TZ_HIP(p->act_scale.upload(d->act_scale, (size_t)mi));
 
-  const size_t doubles = (size_t)p->nquads * 64 + (size_t)Tz * 16 + 10 * (size_t)nzp + 10 * (size_t)mip + 16 + 2;
-  p->lds_bytes = doubles * sizeof(double);
-  hipDeviceProp_t prop;
-  TZ_HIP(hipGetDeviceProperties(&prop, device));
-  if (p->lds_bytes > (size_t)prop.sharedMemPerBlock && p->lds_bytes > 160 * 1024)
+  p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist) * sizeof(double);
+  if (mi > 4 * TZ_THREADS) TZ_FAIL(TZ_ERR_UNSUPPORTED, "mi=%d > %d inequality rows not supported by tz_ipm_kernel", mi, 4 * TZ_THREADS);
+  if (p->lds_bytes > 160 * 1024)
     TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
-  TZ_HIP(hipFuncSetAttribute((const void*)tz_ipm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+  p->maxr = (mi + TZ_THREADS - 1) / TZ_THREADS; p->ncg = (nzp + 63) / 64;
+  p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg);
+  TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+  if (const char* e = getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
+  if (p->prof) TZ_HIP(p->prof_buf.alloc(PH_COUNT));
   TZ_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   p->own_stream = true;
   *out = guard.release();
@@ -497,6 +519,14 @@ int tz_debug_fetch(tz_problem* p, int32_t b, int what, double* out, int32_t capa
     case 3: src = p->x.p + (size_t)b * p->nz; len = p->nz; break;
     case 4: src = p->s.p + (size_t)b * p->mi; len = p->mi; break;
     case 5: src = p->lam.p + (size_t)b * p->mi; len = p->mi; break;
+    case 6: {   // diagnostic build: per-phase cycle sums of workgroup 0 (as doubles)
+      if (!p->prof) TZ_FAIL(TZ_ERR_INVALID, "profiling build not enabled (TZ_PROF=1 at problem creation)");
+      unsigned long long h[PH_COUNT];
+      TZ_HIP(hipMemcpy(h, p->prof_buf.p, sizeof(h), hipMemcpyDeviceToHost));
+      if (capacity < PH_COUNT) TZ_FAIL(TZ_ERR_INVALID, "capacity too small");
+      for (int i = 0; i < PH_COUNT; ++i) out[i] = (double)h[i];
+      return PH_COUNT;
+    }
     default: TZ_FAIL(TZ_ERR_INVALID, "unknown debug item %d", what);
   }
   if (capacity < len) TZ_FAIL(TZ_ERR_INVALID, "capacity %d < %d", capacity, len);

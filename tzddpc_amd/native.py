@@ -38,7 +38,7 @@ class ProblemDesc(C.Structure):
         ("par_lo", _dp), ("par_hi", _dp),
         ("cost_scale", C.c_double), ("r0", C.c_double), ("r1", _dp), ("R2", _dp),
         ("Dz", _dp), ("Phi", _dp), ("Gam", _dp),
-        ("nc_rows", C.c_int32), ("row_of", _ip),
+        ("nc_rows", C.c_int32), ("row_of", _ip), ("act_scale", _dp),
         ("CK", _dp), ("DK", _dp), ("K", _dp), ("pmax", C.c_int32), ("absCKpow", _dp), ("absKCKpow", _dp), ("power", _ip),
         ("max_iter", C.c_int32), ("tol", C.c_double), ("reg", C.c_double), ("step_frac", C.c_double),
     ]
@@ -57,6 +57,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch ships its own copy of the HIP runtime: load it first so that the process ends up with ONE runtime
+        # (loading ours first leaves torch unable to see the GPU).  torch is plumbing here (tensors, streams, RCCL).
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise NativeError(f"{LIB_PATH} not found: the TZDDPC hot path runs only as HIP kernels; {build_hint()}")
     try:
@@ -140,7 +146,7 @@ class Problem:
     """Owner of one ``tz_problem`` handle."""
 
     def __init__(self, device: int, *, n, m, N, P, G, q0, Qt, h0, Ht, par0, Part, par_lo, par_hi, cost_scale, r0, r1, R2,
-                 Dz, Phi, Gam, nc_rows, row_of, CK, DK, K, pmax, absCKpow, absKCKpow, power,
+                 Dz, Phi, Gam, nc_rows, row_of, act_scale, CK, DK, K, pmax, absCKpow, absKCKpow, power,
                  max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99):
         L = lib()
         keep = []
@@ -150,7 +156,7 @@ class Problem:
         P = _f64(P); G = _f64(G)
         d.nz, d.mi = P.shape[0], G.shape[0]
         d.ntheta = 2 * n + N * (2 * n + m)
-        arrs = dict(P=P, G=G, r1=_f64(r1), R2=_f64(R2), Dz=_f64(Dz), Phi=_f64(Phi), Gam=_f64(Gam), CK=_f64(CK), DK=_f64(DK),
+        arrs = dict(P=P, G=G, r1=_f64(r1), R2=_f64(R2), Dz=_f64(Dz), Phi=_f64(Phi), Gam=_f64(Gam), act_scale=_f64(act_scale), CK=_f64(CK), DK=_f64(DK),
                     K=_f64(K), absCKpow=_f64(absCKpow), absKCKpow=_f64(absKCKpow))
         for k, a in arrs.items():
             setattr(d, k, _ptr(a, _dp)); keep.append(a)

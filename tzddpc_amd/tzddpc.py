@@ -200,7 +200,7 @@ class TZDDPC(object):
             q0=c * D * qp.q0, Qt=(c * D)[:, None] * qp.Qt, h0=E * h0, Ht=E[:, None] * Ht,
             par0=qp.f0, Part=qp.Ft, par_lo=qp.pl, par_hi=qp.pu,
             cost_scale=c, r0=qp.r0, r1=qp.r1, R2=qp.R2, Dz=D, Phi=qp.Phi, Gam=qp.Gam,
-            nc_rows=qp.nc, row_of=row_of,
+            nc_rows=qp.nc, row_of=row_of, act_scale=c / (E * E),
             CK=qp.tube.CK, DK=qp.tube.DK, K=qp.tube.K, pmax=qp.tube.pmax,
             absCKpow=qp.tube.absCKpow, absKCKpow=qp.tube.absKCKpow, power=qp.tube.power, **opts)
         self.problem_full = self._native
