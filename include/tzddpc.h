@@ -161,10 +161,19 @@ int tz_simulate_batch(tz_problem* p, int32_t B, int32_t T, const double* x0, con
 int tz_mpc_step(tz_problem* p, int32_t B, double* x, double* xbar, double* e, const double* w,
                 const double* A_true, const double* B_true, double* u_out, double* cost, int32_t* status);
 
+/* K consecutive tz_mpc_step calls issued from one C loop (no host work between steps): w holds the noise of the K steps,
+ * step-major (K x B x n); u_out / cost keep the values of the last step; status is the sticky first non-zero status. */
+int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, double* e, const double* w,
+               const double* A_true, const double* B_true, double* u_out, double* cost, int32_t* status);
+
 /* Kernel timing with HIP events on the problem's stream (bench.py roofline leg).
  * kernel ids: 0 = tz_prepare, 1 = tz_ipm, 2 = tz_finish, 3 = tz_plant_step */
 int tz_timing_enable(tz_problem* p, int enable);
 int tz_timing_get(tz_problem* p, int kernel, double* total_ms, int64_t* launches);
+/* Work done by tz_ipm since tz_timing_enable(p, 1): number of Newton-matrix factorisations (Gram + Cholesky) summed over all
+ * trajectories and launches, and number of trajectory solves.  Counted on the device by the kernel itself. */
+int tz_ipm_work_get(tz_problem* p, int64_t* factorizations, int64_t* trajectory_solves);
+
 /* Static plan of tz_ipm for one trajectory and one interior-point iteration: number of
  * v_mfma_f64_4x4x4 instructions that carry useful tiles in the Gram formation (G'WG, block-sparse) and in
  * the Cholesky trailing updates, the number actually issued (padding included), LDS bytes per workgroup

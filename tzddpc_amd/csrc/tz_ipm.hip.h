@@ -25,7 +25,11 @@ struct IpmParams {
   const int* prestatus;
   double* x; double* s; double* lam;
   int* status; int* iters;
+  const int* prev_status;   // warm start gate: status of the previous closed-loop step (may alias nothing else); null = cold
+  int* status_copy;         // optional second destination of the status (library-owned copy for the next step)
   int max_iter; double tol, reg, step_frac;
+  int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
+  unsigned long long* work;   // [0] += factorisations, [1] += solved trajectories (bench.py roofline accounting); may be null
   unsigned long long* prof;   // TZ_PROF=1: per-phase cycle sums of workgroup 0 (diagnostic; no output depends on it)
 };
 
@@ -137,6 +141,14 @@ __device__ inline double tz_gemvT_get(const double* part, int nzp, int c) {
 // wv: LDS, mip + 4 entries, entries >= mi are zero.  kl: k-lists in LDS.
 struct TzStage { double a[4]; double b[2]; double w; };
 
+// A load the optimiser may neither duplicate nor sink to its use: a relaxed wavefront-scope atomic load is an ordinary
+// global_load in the ISA, but unlike a plain load from read-only memory it cannot be rematerialised, which is what keeps
+// the operand prefetch of the Gram loop several stages ahead of the MFMAs that consume it.
+__device__ inline double tz_ld_pinned(const double* p) {
+  unsigned long long u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  return __builtin_bit_cast(double, u);
+}
+
 __device__ inline void tz_form_H(const IpmParams& p, double* Hq, const double* wv, const int* kl) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
@@ -163,9 +175,9 @@ __device__ inline void tz_form_H(const IpmParams& p, double* Hq, const double* w
       st.w = wv[4 * kc + k];
       const double* prow = gbase + (size_t)kc * rowstride;
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii) { const double* pa = aok[ii] ? prow + aoff[ii] : zrow; st.a[ii] = *pa; }
+      for (int ii = 0; ii < 4; ++ii) { const double* pa = aok[ii] ? prow + aoff[ii] : zrow; st.a[ii] = tz_ld_pinned(pa); }
 #pragma unroll
-      for (int nn = 0; nn < 2; ++nn) { const double* pb = bok[nn] ? prow + boff[nn] : zrow; st.b[nn] = *pb; }
+      for (int nn = 0; nn < 2; ++nn) { const double* pb = bok[nn] ? prow + boff[nn] : zrow; st.b[nn] = tz_ld_pinned(pb); }
     };
     auto fma8 = [&](const TzStage& st) {
 #pragma unroll
@@ -219,64 +231,93 @@ __device__ inline void tz_sqrt_rsqrt(double d, double& sq, double& rs) {
   sq = g; rs = inv;
 }
 
-// In-place blocked Cholesky (tile 4) of the quad-stored matrix.  Off-diagonal tiles of Hq become L; the diagonal tiles are
-// not written back (nothing reads them again): dinv[p] receives the inverse of the diagonal tile's factor.
+template <int JJ>
+__device__ inline double tz_quad_bcast(double v) {                     // value of lane (lane & ~3) + JJ, via DPP quad_perm
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  constexpr int ctrl = JJ * 0x55;
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, ctrl, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), ctrl, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Factor the diagonal tile (pp, pp) (every calling thread redundantly, from LDS) and solve the panel rows of tiles (I, pp),
+// I > pp, with the calling threads tid = 0 .. nthr-1.  Thread tid == 0 stores dinv[pp] = inverse of the diagonal factor.
+// The diagonal tile itself is not written back: nothing reads it again.
+__device__ inline void tz_factor_col(int Tz, double* Hq, double* dinv, int* flag, int pp, int tid, int nthr) {
+  const int dbase = (tz_qprefix(pp) + (pp >> 2)) * 64 + 4 * (pp & 3);
+  const double a00 = Hq[dbase], a10 = Hq[dbase + 16], a11 = Hq[dbase + 17];
+  const double a20 = Hq[dbase + 32], a21 = Hq[dbase + 33], a22 = Hq[dbase + 34];
+  const double a30 = Hq[dbase + 48], a31 = Hq[dbase + 49], a32 = Hq[dbase + 50], a33 = Hq[dbase + 51];
+  bool ok = true;
+  double l00, i00, l11, i11, l22, i22, l33, i33;
+  ok = ok && (a00 > 0.0);
+  tz_sqrt_rsqrt(fmax(a00, 1e-300), l00, i00);
+  const double l10 = a10 * i00, l20 = a20 * i00, l30 = a30 * i00;
+  const double d1 = a11 - l10 * l10; ok = ok && (d1 > 0.0);
+  tz_sqrt_rsqrt(fmax(d1, 1e-300), l11, i11);
+  const double l21 = (a21 - l20 * l10) * i11, l31 = (a31 - l30 * l10) * i11;
+  const double d2 = a22 - l20 * l20 - l21 * l21; ok = ok && (d2 > 0.0);
+  tz_sqrt_rsqrt(fmax(d2, 1e-300), l22, i22);
+  const double l32 = (a32 - l30 * l20 - l31 * l21) * i22;
+  const double d3 = a33 - l30 * l30 - l31 * l31 - l32 * l32; ok = ok && (d3 > 0.0);
+  tz_sqrt_rsqrt(fmax(d3, 1e-300), l33, i33);
+  (void)l00; (void)l11; (void)l22; (void)l33;
+  if (tid == 0) {
+    if (!ok) *flag = 1;
+    const double m10 = -l10 * i00 * i11;
+    const double m21 = -l21 * i11 * i22;
+    const double m32 = -l32 * i22 * i33;
+    const double m20 = -(l20 * i00 + l21 * m10) * i22;
+    const double m31 = -(l31 * i11 + l32 * m21) * i33;
+    const double m30 = -(l30 * i00 + l31 * m10 + l32 * m20) * i33;
+    double* di = dinv + pp * 16;
+    di[0] = i00; di[1] = 0; di[2] = 0; di[3] = 0;
+    di[4] = m10; di[5] = i11; di[6] = 0; di[7] = 0;
+    di[8] = m20; di[9] = m21; di[10] = i22; di[11] = 0;
+    di[12] = m30; di[13] = m31; di[14] = m32; di[15] = i33;
+  }
+  for (int t = tid; t < 4 * (Tz - pp - 1); t += nthr) {      // x L_pp' = a
+    const int I = pp + 1 + (t >> 2), i = t & 3;
+    const int base = (tz_qprefix(I) + (pp >> 2)) * 64 + 16 * i + 4 * (pp & 3);
+    const double b0 = Hq[base], b1 = Hq[base + 1], b2 = Hq[base + 2], b3 = Hq[base + 3];
+    const double x0 = b0 * i00;
+    const double x1 = (b1 - x0 * l10) * i11;
+    const double x2 = (b2 - x0 * l20 - x1 * l21) * i22;
+    const double x3 = (b3 - x0 * l30 - x1 * l31 - x2 * l32) * i33;
+    Hq[base] = x0; Hq[base + 1] = x1; Hq[base + 2] = x2; Hq[base + 3] = x3;
+  }
+}
+
+// In-place tile-4 right-looking Cholesky with look-ahead: after column pp is final, wave 0 alone updates column pp+1,
+// factors its diagonal tile and solves its panel (the latency chain), while waves 1-3 apply column pp to all tiles of the
+// columns >= pp+2 (the bulk, one MFMA per tile row and quad).  One workgroup barrier per column.
 __device__ inline bool tz_cholesky(const IpmParams& p, double* Hq, double* dinv, int* flag) {
   const int Tz = p.Tz;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
-  for (int pp = 0; pp < Tz; ++pp) {
-    const int dbase = (tz_qprefix(pp) + (pp >> 2)) * 64 + 4 * (pp & 3);
-    const double a00 = Hq[dbase], a10 = Hq[dbase + 16], a11 = Hq[dbase + 17];
-    const double a20 = Hq[dbase + 32], a21 = Hq[dbase + 33], a22 = Hq[dbase + 34];
-    const double a30 = Hq[dbase + 48], a31 = Hq[dbase + 49], a32 = Hq[dbase + 50], a33 = Hq[dbase + 51];
-    bool ok = true;
-    double l00, i00, l11, i11, l22, i22, l33, i33;
-    ok = ok && (a00 > 0.0);
-    tz_sqrt_rsqrt(fmax(a00, 1e-300), l00, i00);
-    const double l10 = a10 * i00, l20 = a20 * i00, l30 = a30 * i00;
-    const double d1 = a11 - l10 * l10; ok = ok && (d1 > 0.0);
-    tz_sqrt_rsqrt(fmax(d1, 1e-300), l11, i11);
-    const double l21 = (a21 - l20 * l10) * i11, l31 = (a31 - l30 * l10) * i11;
-    const double d2 = a22 - l20 * l20 - l21 * l21; ok = ok && (d2 > 0.0);
-    tz_sqrt_rsqrt(fmax(d2, 1e-300), l22, i22);
-    const double l32 = (a32 - l30 * l20 - l31 * l21) * i22;
-    const double d3 = a33 - l30 * l30 - l31 * l31 - l32 * l32; ok = ok && (d3 > 0.0);
-    tz_sqrt_rsqrt(fmax(d3, 1e-300), l33, i33);
-    (void)l33;
-    if (threadIdx.x == 0) {
-      if (!ok) *flag = 1;
-      const double m10 = -l10 * i00 * i11;
-      const double m21 = -l21 * i11 * i22;
-      const double m32 = -l32 * i22 * i33;
-      const double m20 = -(l20 * i00 + l21 * m10) * i22;
-      const double m31 = -(l31 * i11 + l32 * m21) * i33;
-      const double m30 = -(l30 * i00 + l31 * m10 + l32 * m20) * i33;
-      double* di = dinv + pp * 16;
-      di[0] = i00; di[1] = 0; di[2] = 0; di[3] = 0;
-      di[4] = m10; di[5] = i11; di[6] = 0; di[7] = 0;
-      di[8] = m20; di[9] = m21; di[10] = i22; di[11] = 0;
-      di[12] = m30; di[13] = m31; di[14] = m32; di[15] = i33;
-    }
-    // panel: rows of tiles (I, pp), I > pp:  x L_pp' = a
-    for (int t = threadIdx.x; t < 4 * (Tz - pp - 1); t += TZ_THREADS) {
-      const int I = pp + 1 + (t >> 2), i = t & 3;
-      const int base = (tz_qprefix(I) + (pp >> 2)) * 64 + 16 * i + 4 * (pp & 3);
-      const double b0 = Hq[base], b1 = Hq[base + 1], b2 = Hq[base + 2], b3 = Hq[base + 3];
-      const double x0 = b0 * i00;
-      const double x1 = (b1 - x0 * l10) * i11;
-      const double x2 = (b2 - x0 * l20 - x1 * l21) * i22;
-      const double x3 = (b3 - x0 * l30 - x1 * l31 - x2 * l32) * i33;
-      Hq[base] = x0; Hq[base + 1] = x1; Hq[base + 2] = x2; Hq[base + 3] = x3;
-    }
-    __syncthreads();
-    // trailing update  H(I, J) -= L(I, pp) L(J, pp)'  for pp < J <= I.  Wave w owns the tile rows I = pp+1+w, pp+5+w, ...;
-    // per row one MFMA per quad, the row's quads issued back to back (independent accumulators).
-    {
-      const int poff = 4 * (pp & 3) + k, pq = pp >> 2, q0 = (pp + 1) >> 2;
-      for (int I = pp + 1 + wave; I < Tz; I += TZ_NWAVES) {
+  const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;       // operand layout (k', blk, i|j); D layout (i = k, blk, j = ij)
+  tz_factor_col(Tz, Hq, dinv, flag, 0, threadIdx.x, TZ_THREADS);
+  __syncthreads();
+  for (int pp = 0; pp + 1 < Tz; ++pp) {
+    const int poff = 4 * (pp & 3) + k, pq = pp >> 2;
+    if (wave == 0) {
+      const int c1 = pp + 1;
+      const double b = Hq[(tz_qprefix(c1) + pq) * 64 + 16 * ij + poff];          // L(4c1 + j, 4pp + k'), j = ij
+      for (int I0 = c1; I0 < Tz; I0 += 4) {
+        const int I = I0 + blk;
+        const bool valid = I < Tz;
+        const int qI = tz_qprefix(valid ? I : c1);
+        const double a = -Hq[(qI + pq) * 64 + 16 * ij + poff];                    // -L(4I + i, 4pp + k'), i = ij
+        const int ci = (qI + (c1 >> 2)) * 64 + 16 * k + 4 * (c1 & 3) + ij;        // H(4I + i', 4c1 + j'), i' = k, j' = ij
+        const double c = Hq[ci];
+        const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+        if (valid) Hq[ci] = d;
+      }
+      tz_factor_col(Tz, Hq, dinv, flag, c1, lane, 64);
+    } else {
+      const int q0 = (pp + 2) >> 2;
+      for (int I = pp + 2 + (wave - 1); I < Tz; I += TZ_NWAVES - 1) {
         const int qI = tz_qprefix(I);
-        const double a = -Hq[(qI + pq) * 64 + 16 * ij + poff];             // -L(4I+i, 4pp+k), i = ij
+        const double a = -Hq[(qI + pq) * 64 + 16 * ij + poff];                    // -L(4I+i, 4pp+k'), i = ij
         const int nq = (I >> 2) - q0 + 1;
         for (int qb = 0; qb < nq; qb += 4) {
           double bb[4], c[4]; bool vd[4]; int ci[4];
@@ -284,12 +325,11 @@ __device__ inline bool tz_cholesky(const IpmParams& p, double* Hq, double* dinv,
           for (int u = 0; u < 4; ++u) {
             const int q = q0 + qb + u;
             const int J = 4 * q + blk;
-            vd[u] = (qb + u < nq) && (J > pp) && (J <= I);
-            ci[u] = (qI + q) * 64 + lane;
-            const int Jc = vd[u] ? J : I;                                            // safe tile for masked lanes
-            const double bl = Hq[(tz_qprefix(Jc) + pq) * 64 + 16 * ij + poff];       // L(4J+j, 4pp+k), j = ij
+            vd[u] = (qb + u < nq) && (J >= pp + 2) && (J <= I);
+            const int Jc = vd[u] ? J : I;                                          // safe tile for masked lanes
+            const double bl = Hq[(tz_qprefix(Jc) + pq) * 64 + 16 * ij + poff];     // L(4J+j, 4pp+k'), j = ij
             bb[u] = vd[u] ? bl : 0.0;
-            ci[u] = vd[u] ? ci[u] : (qI + pq) * 64 + lane;
+            ci[u] = vd[u] ? (qI + q) * 64 + lane : (qI + pq) * 64 + lane;
             c[u] = Hq[ci[u]];
           }
 #pragma unroll
@@ -304,39 +344,86 @@ __device__ inline bool tz_cholesky(const IpmParams& p, double* Hq, double* dinv,
   return *flag == 0;
 }
 
-// Solve (L L') out = rhs.  rhs is destroyed; tmp receives the forward solution.  All in LDS, nzp entries.
+// Solve (L L') out = rhs.  Thread t owns row t (nzp <= 256) in a register; wave w owns the 64-row block w.
+// Forward: the blocks are finished one after the other.  Inside a block the 16 tile steps run wave-synchronously (owner
+// quad finishes its 4 unknowns with DPP broadcasts and publishes them in LDS, the other lanes of the SAME wave pick them up:
+// in-wave LDS ordering, no workgroup barrier); between blocks one barrier and one bulk update of the rows of later blocks.
+// Backward: the mirror image.  ybuf: nzp doubles of LDS.
 __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const double* dinv,
-                                     double* rhs, double* tmp, double* out) {
+                                     const double* rhs, double* ybuf, double* out) {
   const int Tz = p.Tz, nzp = p.nzp;
-  const int t = threadIdx.x;
-  for (int I = 0; I < Tz; ++I) {                 // forward: L y = rhs
-    const double r0 = rhs[4 * I], r1 = rhs[4 * I + 1], r2 = rhs[4 * I + 2], r3 = rhs[4 * I + 3];
-    const double* di = dinv + I * 16;
-    const double y0 = di[0] * r0;
-    const double y1 = di[4] * r0 + di[5] * r1;
-    const double y2 = di[8] * r0 + di[9] * r1 + di[10] * r2;
-    const double y3 = di[12] * r0 + di[13] * r1 + di[14] * r2 + di[15] * r3;
-    if (t == 0) { tmp[4 * I] = y0; tmp[4 * I + 1] = y1; tmp[4 * I + 2] = y2; tmp[4 * I + 3] = y3; }
-    for (int r = 4 * (I + 1) + t; r < nzp; r += TZ_THREADS) {
-      const int base = tz_hidx(r, 4 * I);
-      rhs[r] -= Hq[base] * y0 + Hq[base + 1] * y1 + Hq[base + 2] * y2 + Hq[base + 3] * y3;
+  const int t = threadIdx.x, jq = t & 3, tq = t >> 2, wave = t >> 6;
+  const int nblk = (Tz + 15) >> 4;
+  double rv = (t < nzp) ? rhs[t] : 0.0;
+  const int rowbase = tz_qprefix(tq) * 64 + 16 * jq;                    // + (I>>2)*64 + 4(I&3): L(t, 4I + .)
+  for (int blkI = 0; blkI < nblk; ++blkI) {                             // ---- forward: L y = rhs
+    const int I0 = 16 * blkI, I1 = min(Tz, I0 + 16);
+    if (wave == blkI) {
+      for (int I = I0; I < I1; ++I) {
+        if (tq == I) {
+          const double a0 = tz_quad_bcast<0>(rv), a1 = tz_quad_bcast<1>(rv), a2 = tz_quad_bcast<2>(rv), a3 = tz_quad_bcast<3>(rv);
+          const double* m = dinv + I * 16 + 4 * jq;                      // row jq of M (lower)
+          rv = m[0] * a0 + m[1] * a1 + m[2] * a2 + m[3] * a3;
+          ybuf[t] = rv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tq > I && t < nzp) {
+          const int base = rowbase + (I >> 2) * 64 + 4 * (I & 3);
+          const double* y = ybuf + 4 * I;
+          rv -= Hq[base] * y[0] + Hq[base + 1] * y[1] + Hq[base + 2] * y[2] + Hq[base + 3] * y[3];
+        }
+      }
     }
-    __syncthreads();
-  }
-  for (int I = Tz - 1; I >= 0; --I) {            // backward: L' out = tmp
-    const double y0 = tmp[4 * I], y1 = tmp[4 * I + 1], y2 = tmp[4 * I + 2], y3 = tmp[4 * I + 3];
-    const double* di = dinv + I * 16;            // x = M' y  (M lower)
-    const double x3 = di[15] * y3;
-    const double x2 = di[10] * y2 + di[14] * y3;
-    const double x1 = di[5] * y1 + di[9] * y2 + di[13] * y3;
-    const double x0 = di[0] * y0 + di[4] * y1 + di[8] * y2 + di[12] * y3;
-    if (t == 0) { out[4 * I] = x0; out[4 * I + 1] = x1; out[4 * I + 2] = x2; out[4 * I + 3] = x3; }
-    for (int c = t; c < 4 * I; c += TZ_THREADS) {
-      const int base = (tz_qprefix(I) + (c >> 4)) * 64 + 4 * ((c >> 2) & 3) + (c & 3);
-      tmp[c] -= Hq[base] * x0 + Hq[base + 16] * x1 + Hq[base + 32] * x2 + Hq[base + 48] * x3;
+    if (blkI + 1 < nblk) {
+      __syncthreads();
+      if (wave > blkI && t < nzp) {                                      // bulk: rows of later blocks take this block's y
+        double acc = 0.0;
+        for (int I = I0; I < I1; ++I) {
+          const int base = rowbase + (I >> 2) * 64 + 4 * (I & 3);
+          const double* y = ybuf + 4 * I;
+          acc += Hq[base] * y[0] + Hq[base + 1] * y[1] + Hq[base + 2] * y[2] + Hq[base + 3] * y[3];
+        }
+        rv -= acc;
+      }
     }
-    __syncthreads();
   }
+  const int colbase = (t >> 4) * 64 + 4 * ((t >> 2) & 3) + (t & 3);     // + qprefix(I)*64 + 16k: L(4I + k, t)
+  for (int blkI = nblk - 1; blkI >= 0; --blkI) {                        // ---- backward: L' x = y
+    const int I0 = 16 * blkI, I1 = min(Tz, I0 + 16);
+    if (wave == blkI) {
+      for (int I = I1 - 1; I >= I0; --I) {
+        if (tq == I) {
+          const double y0 = tz_quad_bcast<0>(rv), y1 = tz_quad_bcast<1>(rv), y2 = tz_quad_bcast<2>(rv), y3 = tz_quad_bcast<3>(rv);
+          const double* m = dinv + I * 16 + jq;                          // column jq of M
+          rv = m[0] * y0 + m[4] * y1 + m[8] * y2 + m[12] * y3;
+          ybuf[t] = rv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tq < I && tq >= I0) {
+          const int base = tz_qprefix(I) * 64 + colbase;
+          const double* x = ybuf + 4 * I;
+          rv -= Hq[base] * x[0] + Hq[base + 16] * x[1] + Hq[base + 32] * x[2] + Hq[base + 48] * x[3];
+        }
+      }
+    }
+    if (blkI > 0) {
+      __syncthreads();
+      if (wave < blkI) {                                                 // bulk: rows of earlier blocks take this block's x
+        double acc = 0.0;
+        for (int I = I0; I < I1; ++I) {
+          const int base = tz_qprefix(I) * 64 + colbase;
+          const double* x = ybuf + 4 * I;
+          acc += Hq[base] * x[0] + Hq[base + 16] * x[1] + Hq[base + 32] * x[2] + Hq[base + 48] * x[3];
+        }
+        rv -= acc;
+      }
+    }
+  }
+  if (t < nzp) out[t] = rv;
 }
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
@@ -356,7 +443,7 @@ __global__ __launch_bounds__(TZ_THREADS, 4) void tz_ipm_kernel(IpmParams p) {
   const int t = threadIdx.x;
   const int nz = p.nz, mi = p.mi, nzp = p.nzp, mip = p.mip;
   if (p.prestatus[b] != 0) {
-    if (t == 0) { p.status[b] = 3; p.iters[b] = 0; }
+    if (t == 0) { p.status[b] = 3; p.iters[b] = 0; if (p.status_copy) p.status_copy[b] = 3; }
     for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = 0.0;
     for (int r = t; r < mi; r += TZ_THREADS) { p.s[(size_t)b * mi + r] = 1.0; p.lam[(size_t)b * mi + r] = 0.0; }
     return;
@@ -376,45 +463,20 @@ __global__ __launch_bounds__(TZ_THREADS, 4) void tz_ipm_kernel(IpmParams p) {
   int* kl = (int*)(red + 18);
 
   // rows owned by this thread
-  double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR], w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR];
+  double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR], w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR], is_[MAXR], il_[MAXR];
 #define TZ_ROWS(k, r) _Pragma("unroll") for (int k = 0; k < MAXR; ++k) if (const int r = t + TZ_THREADS * k; r < mi)
 
   for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? p.q[(size_t)b * nz + c] : 0.0; xv[c] = 0.0; }
   for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the start point
   for (int i = t; i < p.nklist; i += TZ_THREADS) kl[i] = p.klist[i];
 #pragma unroll
-  for (int k = 0; k < MAXR; ++k) { s_[k] = 1.0; l_[k] = 0.0; h_[k] = 0.0; gx_[k] = 0.0; w_[k] = 0.0; rp_[k] = 0.0; ds_[k] = 0.0; dl_[k] = 0.0; g_[k] = 0.0; }
+  for (int k = 0; k < MAXR; ++k) { s_[k] = 1.0; l_[k] = 0.0; h_[k] = 0.0; gx_[k] = 0.0; w_[k] = 0.0; rp_[k] = 0.0; ds_[k] = 0.0; dl_[k] = 0.0; g_[k] = 0.0; is_[k] = 1.0; il_[k] = 1.0; }
   TZ_ROWS(k, r) { h_[k] = p.h[(size_t)b * mi + r]; l_[k] = 1.0; }
   if (t == 0) *flag = 0;
   __syncthreads();
 
-  // ---- start point: (P + G'G + reg) x = -q + G'h, then shift the slacks into the cone ----------
-  tz_form_H(p, Hq, vin, kl);
-  __syncthreads();
-  TZ_ROWS(k, r) vin[r] = h_[k];
-  __syncthreads();
-  tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
-  __syncthreads();
-  for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? tz_gemvT_get(part, nzp, c) - qv[c] : 0.0;
-  __syncthreads();
-  const bool okf = tz_cholesky(p, Hq, dinv, flag);
-  tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
-  tz_gemv_G<MAXR>(p, xv, gx_);
-  double scq = 0, sch = 0;
-  {
-    double rmin = 1e300;
-    TZ_ROWS(k, r) { rmin = fmin(rmin, h_[k] - gx_[k]); sch = fmax(sch, fabs(h_[k])); }
-    for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
-    tz_block_reduce3<RED_MIN, RED_MAX, RED_MAX>(rmin, scq, sch, red);
-    const double shift = (rmin <= 1e-8) ? fmax(0.0, 1.0 - rmin) : 0.0;
-    TZ_ROWS(k, r) s_[k] = h_[k] - gx_[k] + shift;
-  }
-  const double sc_d = 1.0 + scq, sc_p = 1.0 + sch;
-
-  int status = okf ? 1 : 2, it = 0;
-  for (it = 0; it < p.max_iter && status == 1; ++it) {
-    TZ_STAMP(PH_ELEM);
-    // residuals: rd = P x + q + G'lam ; rp = G x + s - h ; mu
+  // exact dual residual rd = P x + q + G'lam into rdv (used at the start and to confirm convergence)
+  auto exact_rd = [&]() {
     TZ_ROWS(k, r) vin[r] = l_[k];
     __syncthreads();
     tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
@@ -423,18 +485,74 @@ __global__ __launch_bounds__(TZ_THREADS, 4) void tz_ipm_kernel(IpmParams p) {
     __syncthreads();
     tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
     __syncthreads();
-    TZ_STAMP(PH_GEMVT);
+    for (int c = t; c < nz; c += TZ_THREADS) rdv[c] += tz_gemvT_get(part, nzp, c);
+    __syncthreads();
+  };
+
+  bool okf = true;
+  const bool warm = p.warm != 0 && p.prev_status != nullptr && p.prev_status[b] == 0;     // previous step of this trajectory was solved: start from it
+  if (warm) {
+    // ---- warm start: previous (x, lambda) of this trajectory, slacks re-derived for the new h and pushed into the cone
+    for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + c];
+    __syncthreads();
+    tz_gemv_G<MAXR>(p, xv, gx_);
+    TZ_ROWS(k, r) {
+      s_[k] = fmax(h_[k] - gx_[k], p.warm_floor);
+      l_[k] = fmax(p.lam[(size_t)b * mi + r], p.warm_floor);
+    }
+  } else {
+    // ---- cold start: (P + G'G + reg) x = -q + G'h, then shift the slacks into the cone
+    tz_form_H(p, Hq, vin, kl);
+    __syncthreads();
+    TZ_ROWS(k, r) vin[r] = h_[k];
+    __syncthreads();
+    tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
+    __syncthreads();
+    for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? tz_gemvT_get(part, nzp, c) - qv[c] : 0.0;
+    __syncthreads();
+    okf = tz_cholesky(p, Hq, dinv, flag);
+    tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
+    __syncthreads();
+    tz_gemv_G<MAXR>(p, xv, gx_);
+  }
+  double scq = 0, sch = 0;
+  {
+    double rmin = 1e300;
+    TZ_ROWS(k, r) { rmin = fmin(rmin, h_[k] - gx_[k]); sch = fmax(sch, fabs(h_[k])); }
+    for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
+    tz_block_reduce3<RED_MIN, RED_MAX, RED_MAX>(rmin, scq, sch, red);
+    if (!warm) {
+      const double shift = (rmin <= 1e-8) ? fmax(0.0, 1.0 - rmin) : 0.0;
+      TZ_ROWS(k, r) s_[k] = h_[k] - gx_[k] + shift;
+    }
+  }
+  const double sc_d = 1.0 + scq, sc_p = 1.0 + sch;
+  exact_rd();
+
+  int status = okf ? 1 : 2, it = 0;
+  for (it = 0; it < p.max_iter && status == 1; ++it) {
+    TZ_STAMP(PH_ELEM);
+    // residuals: rd is carried along (Newton on a linear residual: rd <- (1 - alpha) rd) and re-evaluated exactly before
+    // convergence is declared; rp = G x + s - h ; mu
     double nrd = 0, nrp = 0, sl = 0;
-    for (int c = t; c < nz; c += TZ_THREADS) { const double v = rdv[c] + tz_gemvT_get(part, nzp, c); rdv[c] = v; nrd = fmax(nrd, fabs(v)); }
+    for (int c = t; c < nz; c += TZ_THREADS) nrd = fmax(nrd, fabs(rdv[c]));
     TZ_ROWS(k, r) { rp_[k] = gx_[k] + s_[k] - h_[k]; nrp = fmax(nrp, fabs(rp_[k])); sl += s_[k] * l_[k]; }
     tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(nrd, nrp, sl, red);
     const double mu = sl / mi;
     nrd /= sc_d; nrp /= sc_p;
-    if (nrd <= p.tol && nrp <= p.tol && mu <= p.tol) { status = 0; break; }
-    if (mu <= 1e-3 * p.tol) { status = (nrd <= 1e3 * p.tol && nrp <= 1e3 * p.tol) ? 0 : 3; break; }
+    if ((nrd <= p.tol && nrp <= p.tol && mu <= p.tol) || mu <= 1e-3 * p.tol) {
+      exact_rd();
+      double e1 = 0, e2 = 0, e3 = 0;
+      for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
+      tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(e1, e2, e3, red);
+      nrd = e1 / sc_d;
+      TZ_STAMP(PH_GEMVT);
+      if (nrd <= p.tol && nrp <= p.tol && mu <= p.tol) { status = 0; break; }
+      if (mu <= 1e-3 * p.tol) { status = (nrd <= 1e3 * p.tol && nrp <= 1e3 * p.tol) ? 0 : 3; break; }
+    }
     if (!(mu == mu) || !(nrd == nrd) || mu > 1e200) { status = 2; break; }
-    // Newton matrix
-    TZ_ROWS(k, r) { w_[k] = l_[k] / s_[k]; vin[r] = w_[k]; }
+    // Newton matrix.  is = 1/s, il = 1/lambda are the only two divisions per row and iteration.
+    TZ_ROWS(k, r) { is_[k] = 1.0 / s_[k]; il_[k] = 1.0 / l_[k]; w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
     __syncthreads();
     TZ_STAMP(PH_ELEM);
     tz_form_H(p, Hq, vin, kl);
@@ -452,18 +570,21 @@ __global__ __launch_bounds__(TZ_THREADS, 4) void tz_ipm_kernel(IpmParams p) {
     __syncthreads();
     TZ_STAMP(PH_GEMVT);
     tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
+    __syncthreads();
     TZ_STAMP(PH_SOLVE);
     tz_gemv_G<MAXR>(p, dxv, g_);
     TZ_STAMP(PH_GEMV);
-    double ap = 1.0, ad = 1.0, z0 = 0;
+    // step to the boundary: alpha = 1 / max(1, max_i(-dv_i / v_i))
+    double mp = 0.0, md = 0.0, z0 = 0;
     TZ_ROWS(k, r) {
       const double ds = -rp_[k] - g_[k];
       const double dl = -l_[k] - w_[k] * ds;
       ds_[k] = ds; dl_[k] = dl;
-      if (ds < 0) ap = fmin(ap, -s_[k] / ds);
-      if (dl < 0) ad = fmin(ad, -l_[k] / dl);
+      mp = fmax(mp, -ds * is_[k]);
+      md = fmax(md, -dl * il_[k]);
     }
-    tz_block_reduce3<RED_MIN, RED_MIN, RED_SUM>(ap, ad, z0, red);
+    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(mp, md, z0, red);
+    const double ap = 1.0 / fmax(1.0, mp), ad = 1.0 / fmax(1.0, md);
     double muaff = 0, z1 = 0, z2 = 0;
     TZ_ROWS(k, r) muaff += (s_[k] + ap * ds_[k]) * (l_[k] + ad * dl_[k]);
     tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(muaff, z1, z2, red);
@@ -472,7 +593,7 @@ __global__ __launch_bounds__(TZ_THREADS, 4) void tz_ipm_kernel(IpmParams p) {
     // ---- corrector: rc = s*lam + dsa*dla - sigma mu -----------------------------------------------
     TZ_ROWS(k, r) {
       const double rc = s_[k] * l_[k] + ds_[k] * dl_[k] - sigma * mu;
-      vin[r] = (-rc + l_[k] * rp_[k]) / s_[k];
+      vin[r] = (l_[k] * rp_[k] - rc) * is_[k];
       ds_[k] = rc;                                  // keep rc for the dl formula
     }
     __syncthreads();
@@ -483,27 +604,33 @@ __global__ __launch_bounds__(TZ_THREADS, 4) void tz_ipm_kernel(IpmParams p) {
     __syncthreads();
     TZ_STAMP(PH_GEMVT);
     tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
+    __syncthreads();
     TZ_STAMP(PH_SOLVE);
     tz_gemv_G<MAXR>(p, dxv, g_);
     TZ_STAMP(PH_GEMV);
-    double as = 1e300, al = 1e300, z3 = 0;
+    double ms = 0.0, ml = 0.0, z3 = 0;
     TZ_ROWS(k, r) {
       const double rc = ds_[k];
       const double ds = -rp_[k] - g_[k];
-      const double dl = (-rc - l_[k] * ds) / s_[k];
+      const double dl = (-rc - l_[k] * ds) * is_[k];
       ds_[k] = ds; dl_[k] = dl;
-      if (ds < 0) as = fmin(as, -s_[k] / ds);
-      if (dl < 0) al = fmin(al, -l_[k] / dl);
+      ms = fmax(ms, -ds * is_[k]);
+      ml = fmax(ml, -dl * il_[k]);
     }
-    tz_block_reduce3<RED_MIN, RED_MIN, RED_SUM>(as, al, z3, red);
-    const double alpha = fmin(1.0, p.step_frac * fmin(as, al));
-    for (int c = t; c < nz; c += TZ_THREADS) xv[c] += alpha * dxv[c];
+    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(ms, ml, z3, red);
+    const double mm = fmax(ms, ml);
+    const double alpha = (mm * 1.0 > p.step_frac) ? p.step_frac / mm : 1.0;      // min(1, step_frac * min_i(-v_i/dv_i))
+    for (int c = t; c < nz; c += TZ_THREADS) { xv[c] += alpha * dxv[c]; rdv[c] *= (1.0 - alpha); }
     TZ_ROWS(k, r) { s_[k] += alpha * ds_[k]; l_[k] += alpha * dl_[k]; gx_[k] += alpha * g_[k]; }
     __syncthreads();
   }
   for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = xv[c];
   TZ_ROWS(k, r) { p.s[(size_t)b * mi + r] = s_[k]; p.lam[(size_t)b * mi + r] = l_[k]; }
-  if (t == 0) { p.status[b] = status; p.iters[b] = it; }
+  if (t == 0) {
+    p.status[b] = status; p.iters[b] = it;
+    if (p.status_copy) p.status_copy[b] = status;
+    if (p.work) { atomicAdd(p.work, (unsigned long long)(it + (warm ? 0 : 1))); atomicAdd(p.work + 1, 1ull); }
+  }
   if (PROF && t == 0) {
     TZ_STAMP(PH_ELEM);
     acc_ph[PH_TOTAL] = tprev - tstart; acc_ph[7] = (unsigned long long)it;

@@ -42,62 +42,84 @@ struct TubeParams {
   const int* power;      // N
   const double* xbar0; const double* e0;   // B x n
   double* theta;         // B x ntheta
-  double* ws;            // B x (pmax+1) x (3n + m): [c | beta | radx | radu] per power
+  int* prestatus;        // B: cleared here, set by tz_affine_kernel when a parameter-only row is violated
+  double* ws;            // B x (pmax+1) x (3n + m): [c | beta | radx | radu] per power (only when use_lds == 0)
+  int use_lds;
 };
 
-__global__ void tz_tube_kernel(TubeParams p) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= p.B) return;
+// One wave per trajectory.  Lane l keeps beta_l (and beta_{l+64}, ...) in registers; the radius sums over the history
+// are wave reductions, so the recursion costs O(pmax) reduction steps instead of an O(pmax^2) dependent chain per thread.
+#define TZ_TUBE_SLOTS 2      // history entries per lane: pmax <= 64 * TZ_TUBE_SLOTS
+__device__ inline double tz_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__global__ __launch_bounds__(64) void tz_tube_kernel(TubeParams p) {
+  __shared__ double hist[(64 * TZ_TUBE_SLOTS + 1) * (2 * TZ_NMAX + TZ_MMAX)];     // per power: c | radx | radu
+  const int b = blockIdx.x, lane = threadIdx.x;
   const int n = p.n, m = p.m;
-  const int stride = 3 * n + m;
-  double* ws = p.ws + (size_t)b * (p.pmax + 1) * stride;
-  double* th = p.theta + (size_t)b * p.ntheta;
-  for (int i = 0; i < n; ++i) {
-    double x0 = p.xbar0[(size_t)b * n + i];
-    th[i] = x0; th[n + i] = fabs(x0);
-    ws[i] = p.e0[(size_t)b * n + i];          // c^(0)
-    ws[2 * n + i] = 0.0;                      // radx^(0)
-  }
-  for (int j = 0; j < m; ++j) ws[3 * n + j] = 0.0;
+  const int hs = 2 * n + m;
+  double c[TZ_NMAX], rx[TZ_NMAX], ru[TZ_MMAX], beta[TZ_TUBE_SLOTS][TZ_NMAX];
+#pragma unroll
+  for (int i = 0; i < TZ_NMAX; ++i) { c[i] = (i < n) ? p.e0[(size_t)b * n + i] : 0.0; rx[i] = 0.0; }
+#pragma unroll
+  for (int j = 0; j < TZ_MMAX; ++j) ru[j] = 0.0;
+#pragma unroll
+  for (int sl = 0; sl < TZ_TUBE_SLOTS; ++sl)
+#pragma unroll
+    for (int i = 0; i < TZ_NMAX; ++i) beta[sl][i] = 0.0;
+  if (lane == 0) { for (int i = 0; i < n; ++i) { hist[i] = c[i]; hist[n + i] = 0.0; } for (int j = 0; j < m; ++j) hist[2 * n + j] = 0.0; }
   for (int pw = 0; pw < p.pmax; ++pw) {
-    double* cur = ws + (size_t)pw * stride;
-    double* nxt = cur + stride;
-    // beta_pw = DK (|c| + radx)
-    for (int i = 0; i < n; ++i) {
-      double acc = 0.0;
-      for (int j = 0; j < n; ++j) acc += p.DK[i * n + j] * (fabs(cur[j]) + cur[2 * n + j]);
-      cur[n + i] = acc;
+    // beta_pw = DK (|c| + radx)  (uniform), kept by lane pw % 64 in slot pw / 64
+    double bnew[TZ_NMAX], cn[TZ_NMAX];
+#pragma unroll
+    for (int i = 0; i < TZ_NMAX; ++i) {
+      double acc = 0.0, acc2 = 0.0;
+      if (i < n) for (int j = 0; j < n; ++j) { acc += p.DK[i * n + j] * (fabs(c[j]) + rx[j]); acc2 += p.CK[i * n + j] * c[j]; }
+      bnew[i] = acc; cn[i] = acc2;
     }
-    for (int i = 0; i < n; ++i) {
-      double acc = 0.0;
-      for (int j = 0; j < n; ++j) acc += p.CK[i * n + j] * cur[j];
-      nxt[i] = acc;
-    }
-    for (int i = 0; i < n; ++i) {
-      double acc = 0.0;
-      for (int l = 0; l <= pw; ++l) {
-        const double* M = p.absCK + (size_t)(pw - l) * n * n + i * n;
-        const double* beta = ws + (size_t)l * stride + n;
-        for (int j = 0; j < n; ++j) acc += M[j] * beta[j];
+#pragma unroll
+    for (int sl = 0; sl < TZ_TUBE_SLOTS; ++sl)
+      if (lane + 64 * sl == pw) {
+#pragma unroll
+        for (int i = 0; i < TZ_NMAX; ++i) beta[sl][i] = bnew[i];
       }
-      nxt[2 * n + i] = acc;
-    }
-    for (int i = 0; i < m; ++i) {
-      double acc = 0.0;
-      for (int l = 0; l <= pw; ++l) {
-        const double* M = p.absKCK + (size_t)(pw - l) * m * n + i * n;
-        const double* beta = ws + (size_t)l * stride + n;
-        for (int j = 0; j < n; ++j) acc += M[j] * beta[j];
+    // rad^(pw+1) = sum_{l <= pw} |C^(pw-l)| beta_l ,  radU^(pw+1) = sum_l |K C^(pw-l)| beta_l
+    double px[TZ_NMAX], pu[TZ_MMAX];
+#pragma unroll
+    for (int i = 0; i < TZ_NMAX; ++i) px[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < TZ_MMAX; ++j) pu[j] = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < TZ_TUBE_SLOTS; ++sl) {
+      const int l = lane + 64 * sl;
+      if (l <= pw) {
+        const double* Mx = p.absCK + (size_t)(pw - l) * n * n;
+        const double* Mu = p.absKCK + (size_t)(pw - l) * m * n;
+#pragma unroll
+        for (int i = 0; i < TZ_NMAX; ++i) if (i < n) for (int j = 0; j < n; ++j) px[i] += Mx[i * n + j] * beta[sl][j];
+#pragma unroll
+        for (int i = 0; i < TZ_MMAX; ++i) if (i < m) for (int j = 0; j < n; ++j) pu[i] += Mu[i * n + j] * beta[sl][j];
       }
-      nxt[3 * n + i] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < TZ_NMAX; ++i) { if (i < n) rx[i] = tz_wave_sum(px[i]); c[i] = cn[i]; }
+#pragma unroll
+    for (int j = 0; j < TZ_MMAX; ++j) if (j < m) ru[j] = tz_wave_sum(pu[j]);
+    if (lane == 0) {
+      double* h = hist + (size_t)(pw + 1) * hs;
+      for (int i = 0; i < n; ++i) { h[i] = c[i]; h[n + i] = rx[i]; }
+      for (int j = 0; j < m; ++j) h[2 * n + j] = ru[j];
     }
   }
-  const int blk = 2 * n + m;
-  for (int k = 0; k < p.N; ++k) {
-    const double* src = ws + (size_t)p.power[k] * stride;
-    double* dst = th + 2 * n + k * blk;
-    for (int i = 0; i < n; ++i) { dst[i] = src[i]; dst[n + i] = src[2 * n + i]; }
-    for (int j = 0; j < m; ++j) dst[2 * n + j] = src[3 * n + j];
+  __syncthreads();
+  double* th = p.theta + (size_t)b * p.ntheta;
+  if (lane < n) { const double x0 = p.xbar0[(size_t)b * n + lane]; th[lane] = x0; th[n + lane] = fabs(x0); }
+  if (lane == 0) p.prestatus[b] = 0;
+  for (int e = lane; e < p.N * hs; e += 64) {
+    const int k = e / hs, idx = e % hs;
+    th[2 * n + e] = hist[(size_t)p.power[k] * hs + idx];
   }
 }
 

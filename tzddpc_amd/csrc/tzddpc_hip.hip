@@ -89,7 +89,7 @@ struct tz_problem {
   // workspace (capacity Bcap)
   int Bcap = 0;
   DevBuf<double> theta, tube_ws, qv, hv, x, s, lam, v, xbar, cost, in_x0, in_e0;
-  DevBuf<int> prestatus, status, iters, sticky;
+  DevBuf<int> prestatus, status, iters, sticky, prev_status;
   DevBuf<uint8_t> active;
   // closed-loop state / plant (simulate)
   DevBuf<double> st_x, st_xbar, st_e, plantA, plantB, noise, xtraj, utraj, costtraj;
@@ -103,9 +103,12 @@ struct tz_problem {
   int64_t t_count[K_COUNT] = {0, 0, 0, 0};
   int lastB = 0;
   bool prof = false;
+  bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
+  double warm_floor = 1e-3;
+  bool warm_enabled = true;
   int maxr = 1, ncg = 1;
   void (*ipm_fn)(IpmParams) = nullptr;
-  DevBuf<unsigned long long> prof_buf;
+  DevBuf<unsigned long long> prof_buf, work_buf;
 };
 
 namespace {
@@ -130,12 +133,25 @@ int ensure_workspace(tz_problem* p, int B) {
   TZ_HIP(p->status.alloc(b));
   TZ_HIP(p->iters.alloc(b));
   TZ_HIP(p->sticky.alloc(b));
+  TZ_HIP(p->prev_status.alloc(b));
   TZ_HIP(p->active.alloc(b * std::max(p->nc_rows, 1)));
   TZ_HIP(p->st_x.alloc(b * p->n));
   TZ_HIP(p->st_xbar.alloc(b * p->n));
   TZ_HIP(p->st_e.alloc(b * p->n));
   p->Bcap = B;
+  p->have_prev = false;
   return TZ_OK;
+}
+
+void drain_timing_one(tz_problem* p, int k) {
+  for (size_t i = 0; i < p->ev_used[k]; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p->ev_pool[k][i].second) == hipSuccess &&
+        hipEventElapsedTime(&ms, p->ev_pool[k][i].first, p->ev_pool[k][i].second) == hipSuccess) {
+      p->t_ms[k] += ms; p->t_count[k]++;
+    }
+  }
+  p->ev_used[k] = 0;
 }
 
 struct Timer {
@@ -143,9 +159,12 @@ struct Timer {
   Timer(tz_problem* p_, int k_) : p(p_), k(k_) {
     if (!p->timing) return;
     if (p->ev_used[k] == p->ev_pool[k].size()) {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-      p->ev_pool[k].push_back({a, b});
+      if (p->ev_pool[k].size() >= 4096) drain_timing_one(p, k);       // pool exhausted: fold what is recorded (one stream sync)
+      else {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        p->ev_pool[k].push_back({a, b});
+      }
     }
     e0 = p->ev_pool[k][p->ev_used[k]].first; e1 = p->ev_pool[k][p->ev_used[k]].second;
     p->ev_used[k]++;
@@ -155,29 +174,19 @@ struct Timer {
 };
 
 void drain_timing(tz_problem* p) {
-  for (int k = 0; k < K_COUNT; ++k) {
-    for (size_t i = 0; i < p->ev_used[k]; ++i) {
-      float ms = 0.f;
-      if (hipEventSynchronize(p->ev_pool[k][i].second) == hipSuccess &&
-          hipEventElapsedTime(&ms, p->ev_pool[k][i].first, p->ev_pool[k][i].second) == hipSuccess) {
-        p->t_ms[k] += ms; p->t_count[k]++;
-      }
-    }
-    p->ev_used[k] = 0;
-  }
+  for (int k = 0; k < K_COUNT; ++k) drain_timing_one(p, k);
 }
 
 // Core launch sequence on device-resident inputs: tube -> affine -> ipm -> finish.
 int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0,
-                 double* d_v, double* d_xbar, double* d_cost, int* d_status, int* d_iters, uint8_t* d_active, size_t cost_stride = 1) {
+                 double* d_v, double* d_xbar, double* d_cost, int* d_status, int* d_iters, uint8_t* d_active, size_t cost_stride = 1, bool warm = false, bool track_prev = false) {
   hipStream_t st = p->stream;
   p->lastB = B;
-  TZ_HIP(hipMemsetAsync(p->prestatus.p, 0, (size_t)B * sizeof(int), st));
   {
     Timer tm(p, K_TUBE);
     TubeParams tp{B, p->n, p->m, p->N, p->pmax, p->ntheta, p->CK.p, p->DK.p, p->absCK.p, p->absKCK.p, p->power.p,
-                  d_xbar0, d_e0, p->theta.p, p->tube_ws.p};
-    hipLaunchKernelGGL(tz_tube_kernel, dim3((B + 63) / 64), dim3(64), 0, st, tp);
+                  d_xbar0, d_e0, p->theta.p, p->prestatus.p, p->tube_ws.p, 0};
+    hipLaunchKernelGGL(tz_tube_kernel, dim3(B), dim3(64), 0, st, tp);
     AffineParams ap{B, p->ntheta, p->nz, p->mi, p->npar, p->q.view(), p->h.view(), p->par.view(), p->par_lo.p, p->par_hi.p,
                     p->theta.p, p->qv.p, p->hv.p, p->prestatus.p};
     size_t total = (size_t)B * (p->nz + p->mi + p->npar);
@@ -192,7 +201,11 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
     ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
     ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac;
     ip.prof = p->prof ? p->prof_buf.p : nullptr;
+    ip.work = p->timing ? p->work_buf.p : nullptr;
     ip.nklist = p->nklist; ip.nP = p->nP;
+    ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
+    ip.prev_status = warm ? p->prev_status.p : nullptr;
+    ip.status_copy = track_prev ? p->prev_status.p : nullptr;
     hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, st, ip);
   }
   {
@@ -233,6 +246,7 @@ int tz_device_count(int* count) {
 int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (!d || !out) TZ_FAIL(TZ_ERR_INVALID, "null argument");
   if (d->abi_version != TZ_ABI_VERSION) TZ_FAIL(TZ_ERR_INVALID, "abi_version %d != %d", d->abi_version, TZ_ABI_VERSION);
+  if (d->pmax > 64 * TZ_TUBE_SLOTS) TZ_FAIL(TZ_ERR_UNSUPPORTED, "pmax=%d > %d powers of M_K not supported by tz_tube_kernel", d->pmax, 64 * TZ_TUBE_SLOTS);
   if (d->n < 1 || d->n > TZ_NMAX || d->m < 1 || d->m > TZ_MMAX) TZ_FAIL(TZ_ERR_UNSUPPORTED, "dim_x must be 1..%d and dim_u 1..%d", TZ_NMAX, TZ_MMAX);
   if (d->N < 1 || d->nz < d->N * d->m || d->mi < 1) TZ_FAIL(TZ_ERR_INVALID, "inconsistent sizes N=%d nz=%d mi=%d", d->N, d->nz, d->mi);
   if (d->nz > 256) TZ_FAIL(TZ_ERR_UNSUPPORTED, "nz=%d > 256 decision variables not supported by tz_ipm_kernel", d->nz);
@@ -352,7 +366,10 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg);
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
   if (const char* e = getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
+  if (const char* e = getenv("TZ_WARM")) { p->warm_enabled = (e[0] != '0'); }
   if (p->prof) TZ_HIP(p->prof_buf.alloc(PH_COUNT));
+  TZ_HIP(p->work_buf.alloc(2));
+  TZ_HIP(hipMemset(p->work_buf.p, 0, 2 * sizeof(unsigned long long)));
   TZ_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   p->own_stream = true;
   *out = guard.release();
@@ -395,6 +412,7 @@ int tz_solve_batch(tz_problem* p, int32_t B, const double* xbar0, const double* 
   TZ_HIP(hipSetDevice(p->device));
   int rc = ensure_workspace(p, B);
   if (rc) return rc;
+  p->have_prev = false;
   const size_t bn = (size_t)B * p->n * sizeof(double);
   if (mem == TZ_MEM_DEVICE) {
     return launch_solve(p, B, xbar0, e0, v, xbar, cost, status, iters, active);
@@ -422,10 +440,32 @@ int tz_mpc_step(tz_problem* p, int32_t B, double* x, double* xbar, double* e, co
   TZ_HIP(hipSetDevice(p->device));
   int rc = ensure_workspace(p, B);
   if (rc) return rc;
-  rc = launch_solve(p, B, xbar, e, p->v.p, p->xbar.p, cost, status, p->iters.p, nullptr);
+  const bool warm = p->warm_enabled && p->have_prev && p->prevB == B;
+  rc = launch_solve(p, B, xbar, e, p->v.p, p->xbar.p, cost, status, p->iters.p, nullptr, 1, warm, true);
   if (rc) return rc;
+  p->have_prev = true; p->prevB = B;
   return launch_plant(p, B, A_true, B_true, w, (size_t)p->n, p->v.p, p->xbar.p, status, x, xbar, e,
                       u_out, (size_t)p->m, nullptr, 0, nullptr);
+}
+
+int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, double* e, const double* w,
+               const double* A_true, const double* B_true, double* u_out, double* cost, int32_t* status) {
+  if (!p || !x || !xbar || !e || !w || !A_true || !B_true || !cost || !status) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  if (B <= 0 || K <= 0) TZ_FAIL(TZ_ERR_INVALID, "B and K must be positive");
+  TZ_HIP(hipSetDevice(p->device));
+  int rc = ensure_workspace(p, B);
+  if (rc) return rc;
+  TZ_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int), p->stream));
+  for (int t = 0; t < K; ++t) {
+    const bool warm = p->warm_enabled && p->have_prev && p->prevB == B;
+    rc = launch_solve(p, B, xbar, e, p->v.p, p->xbar.p, cost, p->status.p, p->iters.p, nullptr, 1, warm, true);
+    if (rc) return rc;
+    p->have_prev = true; p->prevB = B;
+    rc = launch_plant(p, B, A_true, B_true, w + (size_t)t * B * p->n, (size_t)p->n, p->v.p, p->xbar.p, p->status.p, x, xbar, e,
+                      u_out, (size_t)p->m, nullptr, 0, status);
+    if (rc) return rc;
+  }
+  return TZ_OK;
 }
 
 int tz_simulate_batch(tz_problem* p, int32_t B, int32_t T, const double* x0, const double* noise,
@@ -438,6 +478,7 @@ int tz_simulate_batch(tz_problem* p, int32_t B, int32_t T, const double* x0, con
   if (rc) return rc;
   hipStream_t st = p->stream;
   const int n = p->n, m = p->m;
+  p->have_prev = false;
   const bool host = (mem == TZ_MEM_HOST);
   if (!host && mem != TZ_MEM_DEVICE) TZ_FAIL(TZ_ERR_INVALID, "mem must be TZ_MEM_HOST or TZ_MEM_DEVICE");
   const double *dA = A_true, *dB = B_true, *dnoise = noise;
@@ -459,7 +500,7 @@ int tz_simulate_batch(tz_problem* p, int32_t B, int32_t T, const double* x0, con
   TZ_HIP(hipMemsetAsync(p->st_e.p, 0, (size_t)B * n * sizeof(double), st));                                        // e = 0   (:70)
   TZ_HIP(hipMemsetAsync(p->sticky.p, 0, (size_t)B * sizeof(int), st));
   for (int t = 0; t < T; ++t) {
-    rc = launch_solve(p, B, p->st_xbar.p, p->st_e.p, p->v.p, p->xbar.p, dcost + t, p->status.p, p->iters.p, nullptr, (size_t)T);
+    rc = launch_solve(p, B, p->st_xbar.p, p->st_e.p, p->v.p, p->xbar.p, dcost + t, p->status.p, p->iters.p, nullptr, (size_t)T, p->warm_enabled && t > 0, true);
     if (rc) return rc;
     rc = launch_plant(p, B, dA, dB, dnoise + (size_t)t * n, (size_t)T * n, p->v.p, p->xbar.p, p->status.p,
                       p->st_x.p, p->st_xbar.p, p->st_e.p, du + (size_t)t * m, (size_t)T * m,
@@ -483,6 +524,15 @@ int tz_timing_enable(tz_problem* p, int enable) {
   TZ_HIP(hipSetDevice(p->device));
   if (p->timing) drain_timing(p);
   p->timing = enable != 0;
+  if (p->timing)                                   // events are created here, not inside a timed region
+    for (int k = 0; k < K_COUNT; ++k)
+      while (p->ev_pool[k].size() < 512) {
+        hipEvent_t a, b;
+        TZ_HIP(hipEventCreate(&a)); TZ_HIP(hipEventCreate(&b));
+        p->ev_pool[k].push_back({a, b});
+      }
+  TZ_HIP(hipStreamSynchronize(p->stream));
+  TZ_HIP(hipMemset(p->work_buf.p, 0, 2 * sizeof(unsigned long long)));
   for (int k = 0; k < K_COUNT; ++k) { p->t_ms[k] = 0; p->t_count[k] = 0; }
   return TZ_OK;
 }
@@ -492,6 +542,16 @@ int tz_timing_get(tz_problem* p, int kernel, double* total_ms, int64_t* launches
   TZ_HIP(hipSetDevice(p->device));
   drain_timing(p);
   *total_ms = p->t_ms[kernel]; *launches = p->t_count[kernel];
+  return TZ_OK;
+}
+
+int tz_ipm_work_get(tz_problem* p, int64_t* factorizations, int64_t* trajectory_solves) {
+  if (!p || !factorizations || !trajectory_solves) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  TZ_HIP(hipSetDevice(p->device));
+  TZ_HIP(hipStreamSynchronize(p->stream));
+  unsigned long long h[2];
+  TZ_HIP(hipMemcpy(h, p->work_buf.p, sizeof(h), hipMemcpyDeviceToHost));
+  *factorizations = (int64_t)h[0]; *trajectory_solves = (int64_t)h[1];
   return TZ_OK;
 }
 

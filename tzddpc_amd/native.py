@@ -80,13 +80,15 @@ def lib():
     L.tz_solve_batch.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.tz_simulate_batch.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.tz_mpc_step.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.tz_mpc_run.argtypes = [vp, C.c_int32, C.c_int32] + [vp] * 9
     L.tz_timing_enable.argtypes = [vp, C.c_int]
     L.tz_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.tz_ipm_plan_info.argtypes = [vp] + [C.POINTER(C.c_int64)] * 5
+    L.tz_ipm_work_get.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tz_debug_fetch.argtypes = [vp, C.c_int32, C.c_int, vp, C.c_int32]
     for name in ("tz_device_count", "tz_problem_create", "tz_problem_destroy", "tz_problem_set_stream", "tz_problem_sync",
-                 "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_timing_enable", "tz_timing_get",
-                 "tz_ipm_plan_info", "tz_debug_fetch"):
+                 "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run", "tz_timing_enable", "tz_timing_get",
+                 "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch"):
         getattr(L, name).restype = C.c_int
     if L.tz_abi_version() != TZ_ABI_VERSION:
         raise NativeError(f"ABI mismatch: library {L.tz_abi_version()} vs binding {TZ_ABI_VERSION}")
@@ -95,8 +97,8 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy",
-                    "tz_problem_set_stream", "tz_problem_sync", "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step",
-                    "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_debug_fetch")
+                    "tz_problem_set_stream", "tz_problem_sync", "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run",
+                    "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch")
 
 
 def check(rc: int, what: str):
@@ -217,6 +219,9 @@ class Problem:
     def mpc_step_ptr(self, B, x, xbar, e, w, A_true, B_true, u_out, cost, status):
         check(lib().tz_mpc_step(self._h, int(B), x, xbar, e, w, A_true, B_true, u_out, cost, status), "tz_mpc_step")
 
+    def mpc_run_ptr(self, B, K, x, xbar, e, w, A_true, B_true, u_out, cost, status):
+        check(lib().tz_mpc_run(self._h, int(B), int(K), x, xbar, e, w, A_true, B_true, u_out, cost, status), "tz_mpc_run")
+
     def simulate_batch_ptr(self, B, T, x0, noise, A_true, B_true, x_traj, u_traj, cost, status):
         check(lib().tz_simulate_batch(self._h, int(B), int(T), x0, noise, A_true, B_true, x_traj, u_traj, cost, status,
                                       TZ_MEM_DEVICE), "tz_simulate_batch")
@@ -234,6 +239,11 @@ class Problem:
         ms = C.c_double(0); cnt = C.c_int64(0)
         check(lib().tz_timing_get(self._h, kernel, C.byref(ms), C.byref(cnt)), "tz_timing_get")
         return ms.value, cnt.value
+
+    def work_get(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(lib().tz_ipm_work_get(self._h, C.byref(a), C.byref(b)), "tz_ipm_work_get")
+        return dict(factorizations=a.value, trajectory_solves=b.value)
 
     def plan_info(self):
         a, b, i, c, d = (C.c_int64(0) for _ in range(5))
