@@ -116,6 +116,7 @@ def main():
         run(0, W)
     nat.sync()
     bad |= (status != 0).int()
+    _ = gather_results(torch.cat([cost[:, None], x], dim=1), total)     # warm torch's cat / RCCL paths outside the timed region
     nat.timing_enable(True)
     if world > 1:
         dist.barrier()
