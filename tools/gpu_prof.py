@@ -14,3 +14,4 @@ for case in sys.argv[1:] or ["di_n20"]:
         it = pr[7]
         print(f"{case} B={Bn} wall {dt*1e3:.2f} ms iters(block0) {it:.0f} plan {ctl._native.plan_info()}")
         print("   cycles/iter: " + "  ".join(f"{nm} {pr[i]/max(it+1,1):.0f}" for i, nm in enumerate(names[:7])))
+        if len(pr) > 8: print("   chol detail/iter: update %.0f diag %.0f panel %.0f barriers %.0f" % tuple(pr[8:12] / max(it, 1)))

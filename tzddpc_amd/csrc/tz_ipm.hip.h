@@ -10,6 +10,14 @@
 // row-vector staging buffer, so that four workgroups fit on a CU for the benchmark sizes.
 #pragma once
 
+#ifndef TZ_MINWAVES
+#define TZ_MINWAVES 4
+#endif
+// H lives in LDS as tile rows of quads (4 column tiles); a quad is 4 matrix rows of 16 doubles padded to TZ_QROW = 17 so
+// that neither the MFMA accumulator access (row-major inside the quad) nor the column access of the factorisation and the
+// triangular solves runs into LDS bank conflicts (row stride 16 doubles = 32 banks collides 4- to 8-way).
+#define TZ_QROW 17
+#define TZ_QSTR (4 * TZ_QROW)
 struct IpmItem { int I0, q0, nq, kptr, klen; };
 
 struct IpmParams {
@@ -17,7 +25,7 @@ struct IpmParams {
   const double* P;       // nzp x nzp
   const double* G;       // mip x nzp   (row-major, zero padded)
   const double* Gt;      // nzp x mip   (transpose)
-  const double* Gp;      // (Kc+1) x Tz x 16 patches: Gp[(kc*Tz + J)*16 + 4k + j] = G[4kc+k][4J+j]; row Kc is all zero
+  const double* Gp;      // (Kc+1) x (Tz+1) x 16 patches: Gp[(kc*(Tz+1) + J)*16 + 4k + j] = G[4kc+k][4J+j]; tile Tz of every row and row Kc are zero
   const IpmItem* items;  // Gram work items, grouped per wave
   const int* item_ptr;   // TZ_NWAVES + 1
   const int* klist;
@@ -33,7 +41,7 @@ struct IpmParams {
   unsigned long long* prof;   // TZ_PROF=1: per-phase cycle sums of workgroup 0 (diagnostic; no output depends on it)
 };
 
-enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_COUNT = 8 };
+enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_CH_UPD = 8, PH_CH_DIAG = 9, PH_CH_PANEL = 10, PH_CH_BAR = 11, PH_COUNT = 12 };
 
 __device__ inline int tz_qprefix(int I) {   // number of quads in tile rows < I (row I has (I>>2)+1 quads)
   int a = I >> 2, b = I & 3;
@@ -41,7 +49,7 @@ __device__ inline int tz_qprefix(int I) {   // number of quads in tile rows < I 
 }
 __device__ inline int tz_hidx(int r, int c) {   // LDS index of H(r, c), r >= c (tile-row major, quads in lane order)
   int I = r >> 2, J = c >> 2;
-  return (tz_qprefix(I) + (J >> 2)) * 64 + 16 * (r & 3) + 4 * (J & 3) + (c & 3);
+  return (tz_qprefix(I) + (J >> 2)) * TZ_QSTR + TZ_QROW * (r & 3) + 4 * (J & 3) + (c & 3);
 }
 
 enum { RED_SUM = 0, RED_MAX = 1, RED_MIN = 2 };
@@ -153,31 +161,33 @@ __device__ inline void tz_form_H(const IpmParams& p, double* Hq, const double* w
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
   const int Tz = p.Tz;
-  const size_t rowstride = (size_t)Tz * 16;
-  const double* gbase = p.Gp + 4 * k + ij;
-  for (int it = p.item_ptr[wave]; it < p.item_ptr[wave + 1]; ++it) {
+  // Patch row kc = (Tz + 1) tiles of 16 doubles; tile Tz is all zero (target of masked operands).  The row base is wave
+  // uniform (scalar registers), every operand is  row base + 32-bit lane offset:  no vector address arithmetic per load.
+  const unsigned rowbytes = (unsigned)(Tz + 1) * 128u;
+  const unsigned laneoff = (unsigned)(4 * k + ij) * 8u;
+  const char* gp = (const char*)p.Gp;
+  const int it0 = __builtin_amdgcn_readfirstlane(p.item_ptr[wave]), it1 = __builtin_amdgcn_readfirstlane(p.item_ptr[wave + 1]);
+  for (int it = it0; it < it1; ++it) {
     const IpmItem item = p.items[it];
-    const int* kli = kl + item.kptr;
-    const int klen = item.klen;
+    const int I0 = __builtin_amdgcn_readfirstlane(item.I0), q0 = __builtin_amdgcn_readfirstlane(item.q0);
+    const int nq = __builtin_amdgcn_readfirstlane(item.nq), klen = __builtin_amdgcn_readfirstlane(item.klen);
+    const int* kli = kl + __builtin_amdgcn_readfirstlane(item.kptr);
     double acc[4][2];
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) { acc[ii][0] = 0.0; acc[ii][1] = 0.0; }
-    // operand offsets inside a patch row; invalid tiles point at tile 0 of the all-zero patch row (kc = Kc) instead of
-    // being skipped, so that every load is unconditional (conditional loads end in s_waitcnt vmcnt(0) and kill the prefetch)
-    int aoff[4], boff[2]; bool aok[4], bok[2];
+    unsigned aoff[4], boff[2];
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii) { aok[ii] = item.I0 + ii < Tz; aoff[ii] = aok[ii] ? (item.I0 + ii) * 16 : 0; }
+    for (int ii = 0; ii < 4; ++ii) aoff[ii] = (unsigned)((I0 + ii < Tz) ? (I0 + ii) : Tz) * 128u + laneoff;
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) { const int J = 4 * (item.q0 + nn) + blk; bok[nn] = (nn < item.nq) && (J < Tz); boff[nn] = bok[nn] ? J * 16 : 0; }
-    const double* zrow = gbase + (size_t)p.Kc * rowstride;
+    for (int nn = 0; nn < 2; ++nn) { const int J = 4 * (q0 + nn) + blk; boff[nn] = (unsigned)((nn < nq && J < Tz) ? J : Tz) * 128u + laneoff; }
     auto load = [&](int kk, TzStage& st) {
-      const int kc = kli[kk];                                // lists are padded with Kc (zero patch row) past their end
+      const int kc = __builtin_amdgcn_readfirstlane(kli[kk]);            // lists are padded with Kc (all-zero patch row)
       st.w = wv[4 * kc + k];
-      const double* prow = gbase + (size_t)kc * rowstride;
+      const char* prow = gp + (size_t)kc * rowbytes;                      // scalar
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii) { const double* pa = aok[ii] ? prow + aoff[ii] : zrow; st.a[ii] = tz_ld_pinned(pa); }
+      for (int ii = 0; ii < 4; ++ii) st.a[ii] = tz_ld_pinned((const double*)(prow + aoff[ii]));
 #pragma unroll
-      for (int nn = 0; nn < 2; ++nn) { const double* pb = bok[nn] ? prow + boff[nn] : zrow; st.b[nn] = tz_ld_pinned(pb); }
+      for (int nn = 0; nn < 2; ++nn) st.b[nn] = tz_ld_pinned((const double*)(prow + boff[nn]));
     };
     auto fma8 = [&](const TzStage& st) {
 #pragma unroll
@@ -199,17 +209,17 @@ __device__ inline void tz_form_H(const IpmParams& p, double* Hq, const double* w
     const int i = lane >> 4, j = lane & 3;
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
-      const int I = item.I0 + ii;
+      const int I = I0 + ii;
       if (I >= Tz) continue;
 #pragma unroll
       for (int nn = 0; nn < 2; ++nn) {
-        const int q = item.q0 + nn;
-        if (nn >= item.nq || q > (I >> 2)) continue;
+        const int q = q0 + nn;
+        if (nn >= nq || q > (I >> 2)) continue;
         const int r = 4 * I + i, c = 4 * (4 * q + blk) + j;
         double v = acc[ii][nn];
         if (c < p.nzp) v += p.P[(size_t)r * p.nzp + c];
         if (r == c) v = (r < p.nz) ? v + p.reg : 1.0;
-        Hq[(tz_qprefix(I) + q) * 64 + lane] = v;
+        Hq[(tz_qprefix(I) + q) * TZ_QSTR + TZ_QROW * i + 4 * blk + j] = v;
       }
     }
   }
@@ -243,11 +253,12 @@ __device__ inline double tz_quad_bcast(double v) {                     // value 
 // Factor the diagonal tile (pp, pp) (every calling thread redundantly, from LDS) and solve the panel rows of tiles (I, pp),
 // I > pp, with the calling threads tid = 0 .. nthr-1.  Thread tid == 0 stores dinv[pp] = inverse of the diagonal factor.
 // The diagonal tile itself is not written back: nothing reads it again.
-__device__ inline void tz_factor_col(int Tz, double* Hq, double* dinv, int* flag, int pp, int tid, int nthr) {
-  const int dbase = (tz_qprefix(pp) + (pp >> 2)) * 64 + 4 * (pp & 3);
-  const double a00 = Hq[dbase], a10 = Hq[dbase + 16], a11 = Hq[dbase + 17];
-  const double a20 = Hq[dbase + 32], a21 = Hq[dbase + 33], a22 = Hq[dbase + 34];
-  const double a30 = Hq[dbase + 48], a31 = Hq[dbase + 49], a32 = Hq[dbase + 50], a33 = Hq[dbase + 51];
+__device__ inline void tz_factor_col(int Tz, double* Hq, double* dinv, int* flag, int pp, int tid, int nthr, unsigned long long* pacc = nullptr) {
+  unsigned long long tq0 = pacc ? __builtin_amdgcn_s_memtime() : 0;
+  const int dbase = (tz_qprefix(pp) + (pp >> 2)) * TZ_QSTR + 4 * (pp & 3);
+  const double a00 = Hq[dbase], a10 = Hq[dbase + TZ_QROW], a11 = Hq[dbase + TZ_QROW + 1];
+  const double a20 = Hq[dbase + 2 * TZ_QROW], a21 = Hq[dbase + 2 * TZ_QROW + 1], a22 = Hq[dbase + 2 * TZ_QROW + 2];
+  const double a30 = Hq[dbase + 3 * TZ_QROW], a31 = Hq[dbase + 3 * TZ_QROW + 1], a32 = Hq[dbase + 3 * TZ_QROW + 2], a33 = Hq[dbase + 3 * TZ_QROW + 3];
   bool ok = true;
   double l00, i00, l11, i11, l22, i22, l33, i33;
   ok = ok && (a00 > 0.0);
@@ -262,23 +273,28 @@ __device__ inline void tz_factor_col(int Tz, double* Hq, double* dinv, int* flag
   const double d3 = a33 - l30 * l30 - l31 * l31 - l32 * l32; ok = ok && (d3 > 0.0);
   tz_sqrt_rsqrt(fmax(d3, 1e-300), l33, i33);
   (void)l00; (void)l11; (void)l22; (void)l33;
-  if (tid == 0) {
-    if (!ok) *flag = 1;
+  {
     const double m10 = -l10 * i00 * i11;
     const double m21 = -l21 * i11 * i22;
     const double m32 = -l32 * i22 * i33;
     const double m20 = -(l20 * i00 + l21 * m10) * i22;
     const double m31 = -(l31 * i11 + l32 * m21) * i33;
     const double m30 = -(l30 * i00 + l31 * m10 + l32 * m20) * i33;
-    double* di = dinv + pp * 16;
-    di[0] = i00; di[1] = 0; di[2] = 0; di[3] = 0;
-    di[4] = m10; di[5] = i11; di[6] = 0; di[7] = 0;
-    di[8] = m20; di[9] = m21; di[10] = i22; di[11] = 0;
-    di[12] = m30; di[13] = m31; di[14] = m32; di[15] = i33;
+    if (tid == 0 && !ok) *flag = 1;
+    if (tid < 16) {                       // dinv[pp] = M (lower triangular inverse of the diagonal factor), one entry per lane
+      const int r = tid >> 2, c = tid & 3;
+      double v = 0.0;
+      v = (r == 0 && c == 0) ? i00 : v; v = (r == 1 && c == 0) ? m10 : v; v = (r == 1 && c == 1) ? i11 : v;
+      v = (r == 2 && c == 0) ? m20 : v; v = (r == 2 && c == 1) ? m21 : v; v = (r == 2 && c == 2) ? i22 : v;
+      v = (r == 3 && c == 0) ? m30 : v; v = (r == 3 && c == 1) ? m31 : v; v = (r == 3 && c == 2) ? m32 : v;
+      v = (r == 3 && c == 3) ? i33 : v;
+      dinv[pp * 16 + tid] = v;
+    }
   }
+  if (pacc) { unsigned long long tq1 = __builtin_amdgcn_s_memtime(); pacc[PH_CH_DIAG] += tq1 - tq0; tq0 = tq1; }
   for (int t = tid; t < 4 * (Tz - pp - 1); t += nthr) {      // x L_pp' = a
     const int I = pp + 1 + (t >> 2), i = t & 3;
-    const int base = (tz_qprefix(I) + (pp >> 2)) * 64 + 16 * i + 4 * (pp & 3);
+    const int base = (tz_qprefix(I) + (pp >> 2)) * TZ_QSTR + TZ_QROW * i + 4 * (pp & 3);
     const double b0 = Hq[base], b1 = Hq[base + 1], b2 = Hq[base + 2], b3 = Hq[base + 3];
     const double x0 = b0 * i00;
     const double x1 = (b1 - x0 * l10) * i11;
@@ -286,60 +302,58 @@ __device__ inline void tz_factor_col(int Tz, double* Hq, double* dinv, int* flag
     const double x3 = (b3 - x0 * l30 - x1 * l31 - x2 * l32) * i33;
     Hq[base] = x0; Hq[base + 1] = x1; Hq[base + 2] = x2; Hq[base + 3] = x3;
   }
+  if (pacc) pacc[PH_CH_PANEL] += __builtin_amdgcn_s_memtime() - tq0;
 }
 
-// In-place tile-4 right-looking Cholesky with look-ahead: after column pp is final, wave 0 alone updates column pp+1,
-// factors its diagonal tile and solves its panel (the latency chain), while waves 1-3 apply column pp to all tiles of the
-// columns >= pp+2 (the bulk, one MFMA per tile row and quad).  One workgroup barrier per column.
-__device__ inline bool tz_cholesky(const IpmParams& p, double* Hq, double* dinv, int* flag) {
+// In-place tile-4 LEFT-looking Cholesky.  For tile column pp the tiles (I, pp), I >= pp, are brought up to date with all
+// finished columns k < pp in registers (four tile rows per MFMA = the four blocks; two LDS reads per MFMA and no
+// read-modify-write of H), written once, then the diagonal tile is factored and the panel solved by all threads.
+// Groups of four tile rows are dealt round-robin to the four waves.  Two workgroup barriers per column.
+__device__ inline bool tz_cholesky(const IpmParams& p, double* Hq, double* dinv, int* flag, unsigned long long* pacc = nullptr) {
   const int Tz = p.Tz;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;       // operand layout (k', blk, i|j); D layout (i = k, blk, j = ij)
-  tz_factor_col(Tz, Hq, dinv, flag, 0, threadIdx.x, TZ_THREADS);
-  __syncthreads();
-  for (int pp = 0; pp + 1 < Tz; ++pp) {
-    const int poff = 4 * (pp & 3) + k, pq = pp >> 2;
-    if (wave == 0) {
-      const int c1 = pp + 1;
-      const double b = Hq[(tz_qprefix(c1) + pq) * 64 + 16 * ij + poff];          // L(4c1 + j, 4pp + k'), j = ij
-      for (int I0 = c1; I0 < Tz; I0 += 4) {
-        const int I = I0 + blk;
-        const bool valid = I < Tz;
-        const int qI = tz_qprefix(valid ? I : c1);
-        const double a = -Hq[(qI + pq) * 64 + 16 * ij + poff];                    // -L(4I + i, 4pp + k'), i = ij
-        const int ci = (qI + (c1 >> 2)) * 64 + 16 * k + 4 * (c1 & 3) + ij;        // H(4I + i', 4c1 + j'), i' = k, j' = ij
-        const double c = Hq[ci];
-        const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-        if (valid) Hq[ci] = d;
-      }
-      tz_factor_col(Tz, Hq, dinv, flag, c1, lane, 64);
-    } else {
-      const int q0 = (pp + 2) >> 2;
-      for (int I = pp + 2 + (wave - 1); I < Tz; I += TZ_NWAVES - 1) {
-        const int qI = tz_qprefix(I);
-        const double a = -Hq[(qI + pq) * 64 + 16 * ij + poff];                    // -L(4I+i, 4pp+k'), i = ij
-        const int nq = (I >> 2) - q0 + 1;
-        for (int qb = 0; qb < nq; qb += 4) {
-          double bb[4], c[4]; bool vd[4]; int ci[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int q = q0 + qb + u;
-            const int J = 4 * q + blk;
-            vd[u] = (qb + u < nq) && (J >= pp + 2) && (J <= I);
-            const int Jc = vd[u] ? J : I;                                          // safe tile for masked lanes
-            const double bl = Hq[(tz_qprefix(Jc) + pq) * 64 + 16 * ij + poff];     // L(4J+j, 4pp+k'), j = ij
-            bb[u] = vd[u] ? bl : 0.0;
-            ci[u] = vd[u] ? (qI + q) * 64 + lane : (qI + pq) * 64 + lane;
-            c[u] = Hq[ci[u]];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) c[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb[u], c[u], 0, 0, 0);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) if (vd[u]) Hq[ci[u]] = c[u];
+  for (int pp = 0; pp < Tz; ++pp) {
+    unsigned long long tc0 = pacc ? __builtin_amdgcn_s_memtime() : 0;
+    if (pp > 0) {
+      const int pq = pp >> 2, po = 4 * (pp & 3);
+      const double* pb = Hq + tz_qprefix(pp) * TZ_QSTR + TZ_QROW * ij + k;         // L(4pp + j, 4k2 + k'), j = ij : + off(k2)
+      for (int g = wave; pp + 4 * g < Tz; g += 2 * TZ_NWAVES) {            // two row groups at a time: four independent MFMA chains
+        const int Ia = pp + 4 * g + blk, Ib = Ia + 4 * TZ_NWAVES;
+        const bool va = Ia < Tz, vb = Ib < Tz;
+        const int qa = tz_qprefix(va ? Ia : pp), qb = tz_qprefix(vb ? Ib : pp);
+        const double* pa = Hq + qa * TZ_QSTR + TZ_QROW * ij + k;             // L(4Ia + i, 4k2 + k'), i = ij : + off(k2)
+        const double* pa2 = Hq + qb * TZ_QSTR + TZ_QROW * ij + k;
+        double* pc = Hq + (qa + pq) * TZ_QSTR + TZ_QROW * k + po + ij;       // H(4Ia + i', 4pp + j'), i' = k, j' = ij
+        double* pc2 = Hq + (qb + pq) * TZ_QSTR + TZ_QROW * k + po + ij;
+        double a0 = *pc, a1 = 0.0, c0 = vb ? *pc2 : 0.0, c1 = 0.0;
+        int off = 0, k2 = 0;
+        for (; k2 + 1 < pp; k2 += 2) {
+          const int off1 = off + 4 + (((k2 & 3) == 3) ? TZ_QSTR - 16 : 0);
+          const double nb0 = -pb[off], nb1 = -pb[off1];
+          const double x0 = pa[off], x1 = pa[off1], y0 = pa2[off], y1 = pa2[off1];
+          a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(x0, nb0, a0, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(y0, nb0, c0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(x1, nb1, a1, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(y1, nb1, c1, 0, 0, 0);
+          off = off1 + 4 + ((((k2 + 1) & 3) == 3) ? TZ_QSTR - 16 : 0);
         }
+        if (k2 < pp) {
+          const double nb0 = -pb[off];
+          a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[off], nb0, a0, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa2[off], nb0, c0, 0, 0, 0);
+        }
+        if (va) *pc = a0 + a1;
+        if (vb) *pc2 = c0 + c1;
       }
+      if (pacc) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); pacc[PH_CH_UPD] += t1 - tc0; tc0 = t1; }
+      __syncthreads();
+      if (pacc) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); pacc[PH_CH_BAR] += t1 - tc0; tc0 = t1; }
     }
+    tz_factor_col(Tz, Hq, dinv, flag, pp, threadIdx.x, TZ_THREADS, pacc);
+    if (pacc) tc0 = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (pacc) pacc[PH_CH_BAR] += __builtin_amdgcn_s_memtime() - tc0;
   }
   return *flag == 0;
 }
@@ -355,7 +369,7 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
   const int t = threadIdx.x, jq = t & 3, tq = t >> 2, wave = t >> 6;
   const int nblk = (Tz + 15) >> 4;
   double rv = (t < nzp) ? rhs[t] : 0.0;
-  const int rowbase = tz_qprefix(tq) * 64 + 16 * jq;                    // + (I>>2)*64 + 4(I&3): L(t, 4I + .)
+  const int rowbase = tz_qprefix(tq) * TZ_QSTR + TZ_QROW * jq;                    // + (I>>2)*64 + 4(I&3): L(t, 4I + .)
   for (int blkI = 0; blkI < nblk; ++blkI) {                             // ---- forward: L y = rhs
     const int I0 = 16 * blkI, I1 = min(Tz, I0 + 16);
     if (wave == blkI) {
@@ -370,7 +384,7 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (tq > I && t < nzp) {
-          const int base = rowbase + (I >> 2) * 64 + 4 * (I & 3);
+          const int base = rowbase + (I >> 2) * TZ_QSTR + 4 * (I & 3);
           const double* y = ybuf + 4 * I;
           rv -= Hq[base] * y[0] + Hq[base + 1] * y[1] + Hq[base + 2] * y[2] + Hq[base + 3] * y[3];
         }
@@ -381,7 +395,7 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
       if (wave > blkI && t < nzp) {                                      // bulk: rows of later blocks take this block's y
         double acc = 0.0;
         for (int I = I0; I < I1; ++I) {
-          const int base = rowbase + (I >> 2) * 64 + 4 * (I & 3);
+          const int base = rowbase + (I >> 2) * TZ_QSTR + 4 * (I & 3);
           const double* y = ybuf + 4 * I;
           acc += Hq[base] * y[0] + Hq[base + 1] * y[1] + Hq[base + 2] * y[2] + Hq[base + 3] * y[3];
         }
@@ -389,7 +403,7 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
       }
     }
   }
-  const int colbase = (t >> 4) * 64 + 4 * ((t >> 2) & 3) + (t & 3);     // + qprefix(I)*64 + 16k: L(4I + k, t)
+  const int colbase = (t >> 4) * TZ_QSTR + 4 * ((t >> 2) & 3) + (t & 3);     // + qprefix(I)*64 + 16k: L(4I + k, t)
   for (int blkI = nblk - 1; blkI >= 0; --blkI) {                        // ---- backward: L' x = y
     const int I0 = 16 * blkI, I1 = min(Tz, I0 + 16);
     if (wave == blkI) {
@@ -404,9 +418,9 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (tq < I && tq >= I0) {
-          const int base = tz_qprefix(I) * 64 + colbase;
+          const int base = tz_qprefix(I) * TZ_QSTR + colbase;
           const double* x = ybuf + 4 * I;
-          rv -= Hq[base] * x[0] + Hq[base + 16] * x[1] + Hq[base + 32] * x[2] + Hq[base + 48] * x[3];
+          rv -= Hq[base] * x[0] + Hq[base + TZ_QROW] * x[1] + Hq[base + 2 * TZ_QROW] * x[2] + Hq[base + 3 * TZ_QROW] * x[3];
         }
       }
     }
@@ -415,9 +429,9 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
       if (wave < blkI) {                                                 // bulk: rows of earlier blocks take this block's x
         double acc = 0.0;
         for (int I = I0; I < I1; ++I) {
-          const int base = tz_qprefix(I) * 64 + colbase;
+          const int base = tz_qprefix(I) * TZ_QSTR + colbase;
           const double* x = ybuf + 4 * I;
-          acc += Hq[base] * x[0] + Hq[base + 16] * x[1] + Hq[base + 32] * x[2] + Hq[base + 48] * x[3];
+          acc += Hq[base] * x[0] + Hq[base + TZ_QROW] * x[1] + Hq[base + 2 * TZ_QROW] * x[2] + Hq[base + 3 * TZ_QROW] * x[3];
         }
         rv -= acc;
       }
@@ -428,14 +442,14 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
 __host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist) {
-  return (size_t)nquads * 64 + (size_t)Tz * 16 + 10 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2);
+  return (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 10 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2);
 }
 
 template <int MAXR, int NCG>
-__global__ __launch_bounds__(TZ_THREADS, 4) void tz_ipm_kernel(IpmParams p) {
+__global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmParams p) {
   const bool PROF = p.prof != nullptr && blockIdx.x == 0;
   unsigned long long tprev = 0, tstart = 0;
-  unsigned long long acc_ph[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long acc_ph[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define TZ_STAMP(ph) do { if (PROF) { unsigned long long _t = __builtin_amdgcn_s_memtime(); acc_ph[ph] += _t - tprev; tprev = _t; } } while (0)
   if (PROF) { tprev = __builtin_amdgcn_s_memtime(); tstart = tprev; }
   extern __shared__ double lds[];
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(TZ_THREADS, 4) void tz_ipm_kernel(IpmParams p) {
     return;
   }
   double* Hq = lds;
-  double* dinv = Hq + (size_t)p.nquads * 64;
+  double* dinv = Hq + (size_t)p.nquads * TZ_QSTR;
   double* xv = dinv + p.Tz * 16;
   double* dxv = xv + nzp;
   double* rdv = dxv + nzp;
@@ -558,7 +572,7 @@ __global__ __launch_bounds__(TZ_THREADS, 4) void tz_ipm_kernel(IpmParams p) {
     tz_form_H(p, Hq, vin, kl);
     __syncthreads();
     TZ_STAMP(PH_FORM);
-    if (!tz_cholesky(p, Hq, dinv, flag)) { status = 2; break; }
+    if (!tz_cholesky(p, Hq, dinv, flag, (PROF && t == 0) ? acc_ph : nullptr)) { status = 2; break; }
     TZ_STAMP(PH_CHOL);
     // ---- predictor: rc = s*lam ------------------------------------------------------------------
     TZ_ROWS(k, r) vin[r] = w_[k] * rp_[k] - l_[k];                    // (-rc + lam rp)/s

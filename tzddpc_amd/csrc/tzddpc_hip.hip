@@ -279,12 +279,12 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   for (int I = 0; I < Tz; ++I) p->nquads += (I >> 2) + 1;
 
   // padded dense copies
-  std::vector<double> P((size_t)nzp * nzp, 0.0), G((size_t)mip * nzp, 0.0), Gt((size_t)nzp * mip, 0.0), Gp((size_t)(Kc + 1) * Tz * 16, 0.0);   // last patch row stays zero (prefetch padding)
+  std::vector<double> P((size_t)nzp * nzp, 0.0), G((size_t)mip * nzp, 0.0), Gt((size_t)nzp * mip, 0.0), Gp((size_t)(Kc + 1) * (Tz + 1) * 16, 0.0);   // tile Tz of every row and the last patch row stay zero (masked operands / prefetch padding)
   for (int r = 0; r < nz; ++r) for (int c = 0; c < nz; ++c) P[(size_t)r * nzp + c] = d->P[(size_t)r * nz + c];
   for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) {
     double v = d->G[(size_t)r * nz + c];
     G[(size_t)r * nzp + c] = v; Gt[(size_t)c * mip + r] = v;
-    Gp[((size_t)(r >> 2) * Tz + (c >> 2)) * 16 + 4 * (r & 3) + (c & 3)] = v;
+    Gp[((size_t)(r >> 2) * (Tz + 1) + (c >> 2)) * 16 + 4 * (r & 3) + (c & 3)] = v;
   }
   p->nP = 0;
   for (int r = 0; r < nz; ++r) for (int c = 0; c < nz; ++c) if (P[(size_t)r * nzp + c] != 0.0) p->nP = r + 1;
