@@ -133,3 +133,63 @@ def test_device_pointer_path_equals_host_path(built):
     ctl._native.sync()
     assert np.array_equal(v.cpu().numpy(), host["v"]) and np.array_equal(cost.cpu().numpy(), host["cost"])
     assert (st.cpu().numpy() == 0).all()
+
+
+def test_warm_started_closed_loop_equals_cold(built):
+    """tz_mpc_run / tz_simulate_batch warm-start the interior point from the previous step: same trajectories as cold starts."""
+    import torch
+    from tzddpc_amd.dist import vertex_noise
+    ctl, (A, B, zon) = common.gpu_controller("di_n20")
+    Bn, T = 96, 12
+    noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
+    x0 = np.tile(zon.X0.center, (Bn, 1))
+    warm = ctl.simulate_batch(x0, noise, A, B)
+    # cold reference: step by step through solve_batch (stateless, always cold) with the same plant recursion
+    K = ctl.theta.K
+    x = x0.copy(); xbar = x0.copy(); e = np.zeros_like(x0)
+    xs = [x0.copy()]
+    for t in range(T):
+        out = ctl.solve_batch(xbar, e)
+        assert (out["status"] == 0).all()
+        u = e @ K.T + out["v"][:, 0]
+        x = x @ A.T + u @ B.T + noise[:, t]
+        xbar = out["xbar"][:, 1]; e = x - xbar
+        xs.append(x.copy())
+    xs = np.stack(xs, axis=1)
+    assert (warm["status"] == 0).all()
+    np.testing.assert_allclose(warm["x"], xs, atol=5e-6 * (1 + np.abs(xs).max()))
+    # device-resident multi-step entry point
+    dev = torch.device("cuda", 0)
+    tx = torch.from_numpy(x0.copy()).to(dev); txb = tx.clone(); te = torch.zeros_like(tx)
+    tw = torch.from_numpy(np.ascontiguousarray(noise.transpose(1, 0, 2))).to(dev)
+    tA = torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(dev); tB = torch.from_numpy(np.ascontiguousarray(B, dtype=np.float64)).to(dev)
+    tu = torch.zeros((Bn, 1), dtype=torch.float64, device=dev); tc = torch.zeros(Bn, dtype=torch.float64, device=dev)
+    ts = torch.zeros(Bn, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctl._native.mpc_run_ptr(Bn, T, tx.data_ptr(), txb.data_ptr(), te.data_ptr(), tw.data_ptr(), tA.data_ptr(), tB.data_ptr(),
+                            tu.data_ptr(), tc.data_ptr(), ts.data_ptr())
+    ctl._native.sync()
+    assert (ts.cpu().numpy() == 0).all()
+    np.testing.assert_allclose(tx.cpu().numpy(), xs[:, -1], atol=5e-6 * (1 + np.abs(xs).max()))
+
+
+def test_reference_example_loop_runs_unchanged(built):
+    """examples/di_closed_loop.py = reference examples/1.double_integrator_sim.py:20-95 with only the imports changed."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("di_closed_loop", os.path.join(root, "examples", "di_closed_loop.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    xs, xbars, Ze, zon = mod.main(total_steps=12, verbose=False)
+    Xi = zon.X.interval
+    assert xs.shape == (13, 2) and len(Ze) == 13
+    assert np.all(xs >= Xi.left_limit - 1e-9) and np.all(xs <= Xi.right_limit + 1e-9)
+    assert np.abs(xs[-1]).max() < 1.5                      # regulated towards the origin from (-5, -2)
+    assert Ze[1].num_generators == 24                      # literal Ze[1] of the reference: 24 generators
+
+
+def test_unsupported_sizes_fail_loudly(built):
+    """Horizon 80 of the double integrator needs 312 variables: refused at build time with a clear message, not mis-solved."""
+    from tzddpc_amd import native
+    ctl, (A, B, zon) = common.gpu_controller("di_n5")
+    with pytest.raises(native.NativeError, match="not supported"):
+        ctl.build_problem(80, common.loss_di, common.nocons)
