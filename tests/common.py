@@ -44,7 +44,7 @@ CASES = {
 }
 
 
-def identified_qp(case, seed=25):
+def identified_qp(case, seed=25, epigraph="auto"):
     """Host-only: data -> Mdata -> collapsed parametric QP, without touching the GPU."""
     from tzddpc_amd import TZDDPC
     from tzddpc_amd.builder import build_parametric_qp
@@ -61,7 +61,7 @@ def identified_qp(case, seed=25):
     qp = build_parametric_qp(ctl.Mdata.center[:, :n], ctl.Mdata.center[:, n:], ctl.MdataK.center,
                              ctl.MdataK.single_entry_magnitudes(), ctl.Mdelta.single_entry_magnitudes(), ctl.theta.K,
                              zon.W.center, zon.W.generators, Xi.left_limit, Xi.right_limit, Ui.left_limit, Ui.right_limit,
-                             N, loss, cons, k0)
+                             N, loss, cons, k0, epigraph=epigraph)
     return ctl, qp, (A, B, zon)
 
 

@@ -157,9 +157,27 @@ def term1_power(N: int, k0: Optional[int]) -> np.ndarray:
     return pw
 
 
+def rank_one_factor(Dd: np.ndarray, tol: float = 1e-12):
+    """If Dd = rho s' (what boxing a matrix zonotope built from W x pinv(data) gives: Dd[r,c] = rad(W)_r sum_t|P[t,c]|) return s
+    normalised to max(s) = 1 and the pivot column, else None.  Exact up to rounding: relative residual <= tol."""
+    if not np.any(Dd):
+        return None
+    r0, c0 = np.unravel_index(np.argmax(np.abs(Dd)), Dd.shape)
+    s = Dd[r0] / Dd[r0, c0]
+    rho = Dd[:, c0]
+    if np.abs(Dd - np.outer(rho, s)).max() <= tol * np.abs(Dd).max() and np.all(s >= 0):
+        return s, int(c0)
+    return None
+
+
 def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: int,
                         build_loss: Callable, build_constraints: Optional[Callable],
-                        k0: Optional[int] = None) -> ParametricQP:
+                        k0: Optional[int] = None, epigraph: str = "auto") -> ParametricQP:
+    """epigraph: "component" -- one variable t_{j,c} >= |zeta_{j,c}| per used component (2 rows each);
+                 "aggregate" -- when Delta^delta is rank one (rho s'), every radius depends on t_j only through
+                                tau_j = s'|zeta_j|: one variable per step j and 2^(#components) sign rows
+                                tau_j >= sum_c (+-) s_c zeta_{j,c}.  Same feasible (v, xbar) set, far fewer variables;
+                 "auto"      -- aggregate when available and it has at most 32 sign rows per step (n + m <= 5)."""
     Ahat = np.asarray(Ahat, float); Bhat = np.asarray(Bhat, float)
     K = np.atleast_2d(np.asarray(K, float))
     n, m = Bhat.shape
@@ -205,14 +223,26 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
 
     # ---- which |.| epigraphs are needed --------------------------------------------------------
     used = (np.abs(rxT).sum(axis=(0, 1)) + np.abs(ruT).sum(axis=(0, 1))) > 0      # (nt,)
-    t_var = {}                       # (j, c) -> z index
+    t_var = {}                       # (j, c) -> z index            (component form)
+    tau_var = {}                     # j -> z index                  (aggregate form)
     var_names = [f"v[{k},{j}]" for k in range(N) for j in range(m)]
     nzc = N * m
-    for j in range(N):
-        for c in range(p):
-            if used[j * p + c] and not (j == 0 and c < n):       # |xbar0| is a parameter
-                t_var[(j, c)] = nzc; nzc += 1
-                var_names.append(f"t[{j},{c}]")
+    rk1 = rank_one_factor(Dd) if epigraph in ("auto", "aggregate") else None
+    if epigraph == "aggregate" and rk1 is None:
+        raise StructureError("aggregate epigraphs need a rank-one Delta^delta (boxed W x data structure)")
+    aggregate = rk1 is not None and (epigraph == "aggregate" or int(np.count_nonzero(rk1[0])) <= 5)
+    if aggregate:
+        s_w, c_piv = rk1
+        for j in range(N):
+            if np.any(used[j * p:(j + 1) * p]):
+                tau_var[j] = nzc; nzc += 1
+                var_names.append(f"tau[{j}]")
+    else:
+        for j in range(N):
+            for c in range(p):
+                if used[j * p + c] and not (j == 0 and c < n):       # |xbar0| is a parameter
+                    t_var[(j, c)] = nzc; nzc += 1
+                    var_names.append(f"t[{j},{c}]")
 
     # ---- callbacks on look-alike variables -----------------------------------------------------
     nsym = N * m + N * m + n                       # [v | u_free | xbar0]
@@ -308,10 +338,14 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
             zc = np.zeros(nz); zc[:N * m] = Gam[k][i]
             tt = np.zeros(nz)
             th_abs = zeros_t()
-            for (j, c), zi in t_var.items():
-                tt[zi] = rxT[k][i, j * p + c]
-            for c in range(n):
-                th_abs[ix_ax0(c)] = rxT[k][i, c]             # j = 0, xbar part -> |xbar0|
+            if aggregate:
+                for j, zi in tau_var.items():
+                    tt[zi] = rxT[k][i, j * p + c_piv]            # radius coefficient on tau_j (s normalised to s[c_piv] = 1)
+            else:
+                for (j, c), zi in t_var.items():
+                    tt[zi] = rxT[k][i, j * p + c]
+                for c in range(n):
+                    th_abs[ix_ax0(c)] = rxT[k][i, c]             # j = 0, xbar part -> |xbar0|
             base = zeros_t()
             base[[ix_x0(c) for c in range(n)]] = Phi[k][i]
             base[ix_c(k, i)] += 1.0
@@ -324,17 +358,40 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
         for j2 in range(m):
             zc = np.zeros(nz); zc[k * m + j2] = 1.0
             tt = np.zeros(nz); th_abs = zeros_t()
-            for (j, c), zi in t_var.items():
-                tt[zi] = ruT[k][j2, j * p + c]
-            for c in range(n):
-                th_abs[ix_ax0(c)] = ruT[k][j2, c]
+            if aggregate:
+                for j, zi in tau_var.items():
+                    tt[zi] = ruT[k][j2, j * p + c_piv]
+            else:
+                for (j, c), zi in t_var.items():
+                    tt[zi] = ruT[k][j2, j * p + c]
+                for c in range(n):
+                    th_abs[ix_ax0(c)] = ruT[k][j2, c]
             base = zeros_t()
             for i in range(n):
                 base[ix_c(k, i)] += K[j2, i]
             ruk = zeros_t(); ruk[ix_ru(k, j2)] = 1.0
             add_row(f"Uub[{k},{j2}]", zc + tt, -np.inf, zeros_t(), uu[j2] - Kcn[j2] - ru0[k, j2], -(base + ruk + th_abs))
             add_row(f"Ulb[{k},{j2}]", zc - tt, ul[j2] - Kcn[j2] + ru0[k, j2], -(base - ruk - th_abs), np.inf, zeros_t())
-    # ---- t >= |zeta| ---------------------------------------------------------------------------
+    # ---- tau_j >= s'|zeta_j|  (aggregate form): one row per sign pattern of the components with s_c > 0 -------------
+    if aggregate:
+        import itertools
+        for j, zi in tau_var.items():
+            comps = [c for c in range(p) if s_w[c] > 0]
+            var_c = [c for c in comps if not (j == 0 and c < n)]          # components that depend on decision variables
+            par_c = [c for c in comps if (j == 0 and c < n)]              # xbar0 components: |xbar0| is a parameter
+            for signs in itertools.product((1.0, -1.0), repeat=len(var_c)):
+                zrow = np.zeros(nz); zrow[zi] = 1.0
+                th = zeros_t()
+                for sg, c in zip(signs, var_c):
+                    if c < n:
+                        zrow[:N * m] -= sg * s_w[c] * Gam[j][c]
+                        th[[ix_x0(cc) for cc in range(n)]] += sg * s_w[c] * Phi[j][c]
+                    else:
+                        zrow[j * m + (c - n)] -= sg * s_w[c]
+                for c in par_c:
+                    th[ix_ax0(c)] += s_w[c]
+                add_row(f"tau[{j}]{''.join('+' if sg > 0 else '-' for sg in signs)}", zrow, 0.0, th, np.inf, zeros_t())
+    # ---- t >= |zeta| (component form) ----------------------------------------------------------
     for (j, c), zi in t_var.items():
         zeta = np.zeros(nz); zt = zeros_t()
         if c < n:

@@ -174,7 +174,8 @@ class TZDDPC(object):
         W = self.zonotopes.W
         qp = build_parametric_qp(A, B, self.MdataK.center, DK, Dd, self.theta.K, W.center, W.generators,
                                  Xi.left_limit, Xi.right_limit, Ui.left_limit, Ui.right_limit,
-                                 int(horizon), build_loss, build_constraints, k0)
+                                 int(horizon), build_loss, build_constraints, k0,
+                                 epigraph=str(solver_kwargs.pop("epigraph", "auto")))
         self.qp = qp
         self.horizon = int(horizon)
         self.k0 = k0
