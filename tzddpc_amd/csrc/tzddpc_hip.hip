@@ -104,7 +104,7 @@ struct tz_problem {
   int lastB = 0;
   bool prof = false;
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
-  double warm_floor = 1e-3;
+  double warm_floor = 1e-4;
   bool warm_enabled = true;
   int maxr = 1, ncg = 1;
   void (*ipm_fn)(IpmParams) = nullptr;
@@ -367,6 +367,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
   if (const char* e = getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
   if (const char* e = getenv("TZ_WARM")) { p->warm_enabled = (e[0] != '0'); }
+  if (const char* e = getenv("TZ_WARM_FLOOR")) { double v = atof(e); if (v > 0) p->warm_floor = v; }
   if (p->prof) TZ_HIP(p->prof_buf.alloc(PH_COUNT));
   TZ_HIP(p->work_buf.alloc(2));
   TZ_HIP(hipMemset(p->work_buf.p, 0, 2 * sizeof(unsigned long long)));
