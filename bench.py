@@ -39,7 +39,8 @@ def build_controller(device, horizon):
     rng = np.random.default_rng(25)
     ctl = TZDDPC(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, rng), device=device)
     ctl.build_zonotopes_theta(zon)
-    ctl.build_problem(horizon, di_loss, lambda u, x: [])
+    kw = {"tol": float(os.environ["TZ_TOL"])} if "TZ_TOL" in os.environ else {}
+    ctl.build_problem(horizon, di_loss, lambda u, x: [], **kw)
     return ctl, A, B, zon
 
 
@@ -82,10 +83,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or "RANK" in os.environ            # under torch.distributed.run even one rank goes through RCCL
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     ctl, A, Bm, zon = build_controller(local_rank, args.horizon)
@@ -118,7 +121,7 @@ def main():
     bad |= (status != 0).int()
     _ = gather_results(torch.cat([cost[:, None], x], dim=1), total)     # warm torch's cat / RCCL paths outside the timed region
     nat.timing_enable(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(); nat.sync()
     t0 = time.perf_counter()
@@ -126,7 +129,7 @@ def main():
     nat.sync()
     gathered = gather_results(torch.cat([cost[:, None], x], dim=1), total)    # per-trajectory cost + final state only
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ipm_ms, ipm_n = nat.timing_get(1)
@@ -134,7 +137,7 @@ def main():
     bad |= (status != 0).int()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     nbad = bad.sum().to(torch.float64).reshape(1)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nbad, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
@@ -165,13 +168,14 @@ def main():
                          "flop_per_launch": flop_per_launch,
                          "note": "useful v_mfma_f64_4x4x4 flops of the static plan (Gram G'WG + Cholesky trailing updates) x factorisations counted on the device"},
         }
+        line["config"]["gathered_rows"] = int(gathered.shape[0])
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(ctl, A, Bm, zon, args.horizon)
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "MPC steps/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
