@@ -39,9 +39,10 @@ struct IpmParams {
   int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
   unsigned long long* work;   // [0] += factorisations, [1] += solved trajectories (bench.py roofline accounting); may be null
   unsigned long long* prof;   // TZ_PROF=1: per-phase cycle sums of workgroup 0 (diagnostic; no output depends on it)
+  FuseParams F;               // F.on != 0: whole closed-loop step in this launch (q, h, prestatus above are then unused)
 };
 
-enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_CH_UPD = 8, PH_CH_DIAG = 9, PH_CH_PANEL = 10, PH_CH_BAR = 11, PH_COUNT = 12 };
+enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_CH_UPD = 8, PH_CH_DIAG = 9, PH_CH_PANEL = 10, PH_CH_BAR = 11, PH_PROLOGUE = 12, PH_EPILOGUE = 13, PH_COUNT = 14 };
 
 __device__ inline int tz_qprefix(int I) {   // number of quads in tile rows < I (row I has (I>>2)+1 quads)
   int a = I >> 2, b = I & 3;
@@ -441,22 +442,24 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
 }
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
-__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist) {
-  return (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 10 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2);
+__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta) {
+  return (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 10 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta;
 }
 
 template <int MAXR, int NCG>
 __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmParams p) {
   const bool PROF = p.prof != nullptr && blockIdx.x == 0;
   unsigned long long tprev = 0, tstart = 0;
-  unsigned long long acc_ph[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long acc_ph[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define TZ_STAMP(ph) do { if (PROF) { unsigned long long _t = __builtin_amdgcn_s_memtime(); acc_ph[ph] += _t - tprev; tprev = _t; } } while (0)
   if (PROF) { tprev = __builtin_amdgcn_s_memtime(); tstart = tprev; }
   extern __shared__ double lds[];
   const int b = blockIdx.x;
   const int t = threadIdx.x;
   const int nz = p.nz, mi = p.mi, nzp = p.nzp, mip = p.mip;
-  if (p.prestatus[b] != 0) {
+  const FuseParams& F = p.F;
+  const bool fused = F.on != 0;          // closed-loop step in one launch: tube + parameter maps before, recovery + plant after
+  if (!fused && p.prestatus[b] != 0) {
     if (t == 0) { p.status[b] = 3; p.iters[b] = 0; if (p.status_copy) p.status_copy[b] = 3; }
     for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = 0.0;
     for (int r = t; r < mi; r += TZ_THREADS) { p.s[(size_t)b * mi + r] = 1.0; p.lam[(size_t)b * mi + r] = 0.0; }
@@ -475,19 +478,35 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   double* red = vin + mip + 4;            // 16
   int* flag = (int*)(red + 16);
   int* kl = (int*)(red + 18);
+  double* thl = red + 18 + (p.nklist + 1) / 2;      // theta of this trajectory (fused step only)
 
   // rows owned by this thread
   double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR], w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR], is_[MAXR], il_[MAXR];
 #define TZ_ROWS(k, r) _Pragma("unroll") for (int k = 0; k < MAXR; ++k) if (const int r = t + TZ_THREADS * k; r < mi)
 
+  bool skip = false;                        // fused step: a parameter row is violated -> status 3, u = K e, nominal state from Phi
+  if (fused) {
+    if (t == 0) { flag[0] = 0; flag[1] = 0; }
+    tz_tube_block(F.tube, b, Hq, thl, t, TZ_THREADS);       // the factor storage is free until the first Gram
+    __syncthreads();
+    for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? csr_row(F.qmap, c, thl) : 0.0; xv[c] = 0.0; }
+    int bad = 0;
+    for (int r = t; r < F.npar; r += TZ_THREADS) {
+      const double v = csr_row(F.parmap, r, thl);
+      if (!(v >= F.par_lo[r] - 1e-9) || !(v <= F.par_hi[r] + 1e-9)) bad = 1;
+    }
+    if (bad) flag[1] = 1;
+  } else
   for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? p.q[(size_t)b * nz + c] : 0.0; xv[c] = 0.0; }
   for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the start point
   for (int i = t; i < p.nklist; i += TZ_THREADS) kl[i] = p.klist[i];
 #pragma unroll
   for (int k = 0; k < MAXR; ++k) { s_[k] = 1.0; l_[k] = 0.0; h_[k] = 0.0; gx_[k] = 0.0; w_[k] = 0.0; rp_[k] = 0.0; ds_[k] = 0.0; dl_[k] = 0.0; g_[k] = 0.0; is_[k] = 1.0; il_[k] = 1.0; }
-  TZ_ROWS(k, r) { h_[k] = p.h[(size_t)b * mi + r]; l_[k] = 1.0; }
-  if (t == 0) *flag = 0;
+  if (fused) { TZ_ROWS(k, r) { h_[k] = csr_row(F.hmap, r, thl); l_[k] = 1.0; } }
+  else { TZ_ROWS(k, r) { h_[k] = p.h[(size_t)b * mi + r]; l_[k] = 1.0; } if (t == 0) *flag = 0; }
   __syncthreads();
+  if (fused && flag[1] != 0) { skip = true; TZ_ROWS(k, r) l_[k] = 0.0; }
+  TZ_STAMP(PH_PROLOGUE);
 
   // exact dual residual rd = P x + q + G'lam into rdv (used at the start and to confirm convergence)
   auto exact_rd = [&]() {
@@ -504,7 +523,9 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   };
 
   bool okf = true;
-  const bool warm = p.warm != 0 && p.prev_status != nullptr && p.prev_status[b] == 0;     // previous step of this trajectory was solved: start from it
+  const bool warm = !skip && p.warm != 0 && p.prev_status != nullptr && p.prev_status[b] == 0;     // previous step of this trajectory was solved: start from it
+  double scq = 0, sch = 0;
+  if (!skip) {
   if (warm) {
     // ---- warm start: previous (x, lambda) of this trajectory, slacks re-derived for the new h and pushed into the cone
     for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + c];
@@ -529,7 +550,6 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     __syncthreads();
     tz_gemv_G<MAXR>(p, xv, gx_);
   }
-  double scq = 0, sch = 0;
   {
     double rmin = 1e300;
     TZ_ROWS(k, r) { rmin = fmin(rmin, h_[k] - gx_[k]); sch = fmax(sch, fabs(h_[k])); }
@@ -540,10 +560,11 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       TZ_ROWS(k, r) s_[k] = h_[k] - gx_[k] + shift;
     }
   }
-  const double sc_d = 1.0 + scq, sc_p = 1.0 + sch;
   exact_rd();
+  }
+  const double sc_d = 1.0 + scq, sc_p = 1.0 + sch;
 
-  int status = okf ? 1 : 2, it = 0;
+  int status = skip ? 3 : (okf ? 1 : 2), it = 0;
   for (it = 0; it < p.max_iter && status == 1; ++it) {
     TZ_STAMP(PH_ELEM);
     // residuals: rd is carried along (Newton on a linear residual: rd <- (1 - alpha) rd) and re-evaluated exactly before
@@ -645,8 +666,62 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     if (p.status_copy) p.status_copy[b] = status;
     if (p.work) { atomicAdd(p.work, (unsigned long long)(it + (warm ? 0 : 1))); atomicAdd(p.work + 1, 1ull); }
   }
+  TZ_STAMP(PH_ELEM);
+  if (fused) {
+    // ---- recovery (tz_finish_kernel) and plant / error update (tz_plant_kernel) of this trajectory ----------------
+    const int n = F.fin.n, m = F.fin.m, N = F.fin.N, nv = N * m;
+    const double* x0 = F.fin.xbar0 + (size_t)b * n;
+    __syncthreads();
+    tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
+    for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = F.fin.Dz[c] * xv[c];
+    __syncthreads();
+    double acc = 0.0, z1 = 0.0, z2 = 0.0;
+    for (int c = t; c < nz; c += TZ_THREADS) acc += xv[c] * (0.5 * tz_gemvT_get(part, nzp, c) + qv[c]);
+    tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(acc, z1, z2, red);
+    if (t == 0) {
+      double r = F.fin.r0;
+      for (int i = 0; i < n; ++i) {
+        r += F.fin.r1[i] * x0[i];
+        for (int j = 0; j < n; ++j) r += x0[i] * F.fin.R2[i * n + j] * x0[j];
+      }
+      F.fin.cost[(size_t)b * F.fin.cost_stride] = (status == 0 || status == 1) ? acc / F.fin.cost_scale + r : INFINITY;
+      if (F.plant.sticky && F.plant.sticky[b] == 0 && status != 0) F.plant.sticky[b] = status;
+    }
+    if (F.fin.v) for (int c = t; c < nv; c += TZ_THREADS) F.fin.v[(size_t)b * nv + c] = dxv[c];
+    for (int r = t; r < (N + 1) * n; r += TZ_THREADS) {
+      double a = 0.0;
+      for (int j = 0; j < n; ++j) a += F.fin.Phi[(size_t)r * n + j] * x0[j];
+      const double* g = F.fin.Gam + (size_t)r * nv;
+      for (int c = 0; c < nv; ++c) a += g[c] * dxv[c];
+      if (F.fin.xbar) F.fin.xbar[(size_t)b * (N + 1) * n + r] = a;
+      if (r >= n && r < 2 * n) tmpz[r - n] = a;
+    }
+    __syncthreads();
+    if (t < 64) {
+      const PlantParams& Q = F.plant;
+      double xn = 0.0, xb = 0.0;
+      if (t < n) {
+        xn = Q.w[(size_t)b * Q.w_stride + t];
+        for (int j = 0; j < n; ++j) xn += Q.A[t * n + j] * Q.x[(size_t)b * n + j];
+        for (int j = 0; j < m; ++j) {
+          double u = dxv[j];
+          for (int i = 0; i < n; ++i) u += Q.K[j * n + i] * Q.e[(size_t)b * n + i];
+          xn += Q.Bm[t * m + j] * u;
+          if (t == 0 && Q.u_out) Q.u_out[(size_t)b * Q.u_stride + j] = u;
+        }
+        xb = tmpz[t];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                       // every lane has read the old state before any lane overwrites it
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (t < n) {
+        Q.x[(size_t)b * n + t] = xn; Q.xbar[(size_t)b * n + t] = xb; Q.e[(size_t)b * n + t] = xn - xb;
+        if (Q.x_out) Q.x_out[(size_t)b * Q.x_stride + t] = xn;
+      }
+    }
+  }
   if (PROF && t == 0) {
-    TZ_STAMP(PH_ELEM);
+    TZ_STAMP(PH_EPILOGUE);
     acc_ph[PH_TOTAL] = tprev - tstart; acc_ph[7] = (unsigned long long)it;
     for (int i = 0; i < PH_COUNT; ++i) p.prof[i] = acc_ph[i];
   }

@@ -29,98 +29,62 @@ struct TzCsr {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Tube propagation: one thread per trajectory.
+// Tube propagation from e0 (reference tzddpc/tzddpc.py:172-181,191-192).
 //   Z^(0) = <e0>;  Z^(p+1) = M_K Z^(p):  c^(p+1) = C_K c^(p),  beta_p = D_K (|c^(p)| + rad^(p)),
 //   rad^(p+1) = sum_{l<=p} |C_K^(p-l)| beta_l,   radU^(p+1) = sum_{l<=p} |K C_K^(p-l)| beta_l
+// Given a_l = |c^(l)| the recursion is linear with nonnegative coefficients, so its resolvent is a constant of the
+// problem (block lower-triangular Toeplitz, built once on the host in tz_problem_create):
+//   rad^(p) = sum_{l<p} Tx_{p-1-l} a_l ,  radU^(p) = sum_{l<p} Tu_{p-1-l} a_l ,  c^(l) = C_K^l e0
+// which turns an O(pmax) dependent chain into two short parallel passes.
 // theta = [xbar0 | |xbar0| | (c_k, rho^x_k, rho^u_k) for k < N] with step k taking power[k].
 // ------------------------------------------------------------------------------------------------
 struct TubeParams {
   int B, n, m, N, pmax, ntheta;
-  const double* CK; const double* DK;
-  const double* absCK;   // pmax x n x n
-  const double* absKCK;  // pmax x m x n
+  const double* CKpow;   // (pmax+1) x n x n      C_K^l
+  const double* T;       // pmax x (n+m) x n      [Tx_d ; Tu_d]
   const int* power;      // N
   const double* xbar0; const double* e0;   // B x n
   double* theta;         // B x ntheta
   int* prestatus;        // B: cleared here, set by tz_affine_kernel when a parameter-only row is violated
-  double* ws;            // B x (pmax+1) x (3n + m): [c | beta | radx | radu] per power (only when use_lds == 0)
-  int use_lds;
 };
 
-// One wave per trajectory.  Lane l keeps beta_l (and beta_{l+64}, ...) in registers; the radius sums over the history
-// are wave reductions, so the recursion costs O(pmax) reduction steps instead of an O(pmax^2) dependent chain per thread.
-#define TZ_TUBE_SLOTS 2      // history entries per lane: pmax <= 64 * TZ_TUBE_SLOTS
-__device__ inline double tz_wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__global__ __launch_bounds__(64) void tz_tube_kernel(TubeParams p) {
-  __shared__ double hist[(64 * TZ_TUBE_SLOTS + 1) * (2 * TZ_NMAX + TZ_MMAX)];     // per power: c | radx | radu
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const int n = p.n, m = p.m;
-  const int hs = 2 * n + m;
-  double c[TZ_NMAX], rx[TZ_NMAX], ru[TZ_MMAX], beta[TZ_TUBE_SLOTS][TZ_NMAX];
-#pragma unroll
-  for (int i = 0; i < TZ_NMAX; ++i) { c[i] = (i < n) ? p.e0[(size_t)b * n + i] : 0.0; rx[i] = 0.0; }
-#pragma unroll
-  for (int j = 0; j < TZ_MMAX; ++j) ru[j] = 0.0;
-#pragma unroll
-  for (int sl = 0; sl < TZ_TUBE_SLOTS; ++sl)
-#pragma unroll
-    for (int i = 0; i < TZ_NMAX; ++i) beta[sl][i] = 0.0;
-  if (lane == 0) { for (int i = 0; i < n; ++i) { hist[i] = c[i]; hist[n + i] = 0.0; } for (int j = 0; j < m; ++j) hist[2 * n + j] = 0.0; }
-  for (int pw = 0; pw < p.pmax; ++pw) {
-    // beta_pw = DK (|c| + radx)  (uniform), kept by lane pw % 64 in slot pw / 64
-    double bnew[TZ_NMAX], cn[TZ_NMAX];
-#pragma unroll
-    for (int i = 0; i < TZ_NMAX; ++i) {
-      double acc = 0.0, acc2 = 0.0;
-      if (i < n) for (int j = 0; j < n; ++j) { acc += p.DK[i * n + j] * (fabs(c[j]) + rx[j]); acc2 += p.CK[i * n + j] * c[j]; }
-      bnew[i] = acc; cn[i] = acc2;
-    }
-#pragma unroll
-    for (int sl = 0; sl < TZ_TUBE_SLOTS; ++sl)
-      if (lane + 64 * sl == pw) {
-#pragma unroll
-        for (int i = 0; i < TZ_NMAX; ++i) beta[sl][i] = bnew[i];
-      }
-    // rad^(pw+1) = sum_{l <= pw} |C^(pw-l)| beta_l ,  radU^(pw+1) = sum_l |K C^(pw-l)| beta_l
-    double px[TZ_NMAX], pu[TZ_MMAX];
-#pragma unroll
-    for (int i = 0; i < TZ_NMAX; ++i) px[i] = 0.0;
-#pragma unroll
-    for (int j = 0; j < TZ_MMAX; ++j) pu[j] = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < TZ_TUBE_SLOTS; ++sl) {
-      const int l = lane + 64 * sl;
-      if (l <= pw) {
-        const double* Mx = p.absCK + (size_t)(pw - l) * n * n;
-        const double* Mu = p.absKCK + (size_t)(pw - l) * m * n;
-#pragma unroll
-        for (int i = 0; i < TZ_NMAX; ++i) if (i < n) for (int j = 0; j < n; ++j) px[i] += Mx[i * n + j] * beta[sl][j];
-#pragma unroll
-        for (int i = 0; i < TZ_MMAX; ++i) if (i < m) for (int j = 0; j < n; ++j) pu[i] += Mu[i * n + j] * beta[sl][j];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < TZ_NMAX; ++i) { if (i < n) rx[i] = tz_wave_sum(px[i]); c[i] = cn[i]; }
-#pragma unroll
-    for (int j = 0; j < TZ_MMAX; ++j) if (j < m) ru[j] = tz_wave_sum(pu[j]);
-    if (lane == 0) {
-      double* h = hist + (size_t)(pw + 1) * hs;
-      for (int i = 0; i < n; ++i) { h[i] = c[i]; h[n + i] = rx[i]; }
-      for (int j = 0; j < m; ++j) h[2 * n + j] = ru[j];
-    }
+#define TZ_PMAX 128        // highest supported power of M_K
+// All nt threads of the workgroup (tid) work on trajectory b.  aL: pmax * n doubles of LDS scratch; th: ntheta doubles (LDS or
+// global).  Contains one workgroup barrier; the caller adds another before th is read by other threads.
+__device__ inline void tz_tube_block(const TubeParams& p, int b, double* aL, double* th, int tid, int nt) {
+  const int n = p.n, m = p.m, hs = 2 * n + m;
+  const double* e0 = p.e0 + (size_t)b * n;
+  for (int e = tid; e < p.pmax * n; e += nt) {
+    const double* M = p.CKpow + (size_t)e * n;            // row i of C_K^l with e = l n + i
+    double a = 0.0;
+    for (int j = 0; j < n; ++j) a += M[j] * e0[j];
+    aL[e] = fabs(a);
   }
+  if (tid < n) { const double x0 = p.xbar0[(size_t)b * n + tid]; th[tid] = x0; th[n + tid] = fabs(x0); }
   __syncthreads();
-  double* th = p.theta + (size_t)b * p.ntheta;
-  if (lane < n) { const double x0 = p.xbar0[(size_t)b * n + lane]; th[lane] = x0; th[n + lane] = fabs(x0); }
-  if (lane == 0) p.prestatus[b] = 0;
-  for (int e = lane; e < p.N * hs; e += 64) {
-    const int k = e / hs, idx = e % hs;
-    th[2 * n + e] = hist[(size_t)p.power[k] * hs + idx];
+  for (int e = tid; e < p.N * hs; e += nt) {
+    const int k = e / hs, idx = e % hs, pw = p.power[k];
+    double a = 0.0;
+    if (idx < n) {
+      const double* M = p.CKpow + ((size_t)pw * n + idx) * n;
+      for (int j = 0; j < n; ++j) a += M[j] * e0[j];
+    } else {
+      const int comp = idx - n;
+      const double* T = p.T + ((size_t)(pw - 1) * (n + m) + comp) * n;     // walks down as l goes up
+      const double* al = aL;
+#pragma unroll 4
+      for (int l = 0; l < pw; ++l, T -= (size_t)(n + m) * n, al += n)
+        for (int j = 0; j < n; ++j) a += T[j] * al[j];
+    }
+    th[2 * n + e] = a;
   }
+}
+
+__global__ __launch_bounds__(64) void tz_tube_kernel(TubeParams p) {
+  __shared__ double aL[TZ_PMAX * TZ_NMAX];
+  const int b = blockIdx.x;
+  tz_tube_block(p, b, aL, p.theta + (size_t)b * p.ntheta, threadIdx.x, 64);
+  if (threadIdx.x == 0) p.prestatus[b] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -160,11 +124,6 @@ __global__ void tz_affine_kernel(AffineParams p) {
   }
 }
 
-#include "tz_ipm.hip.h"
-
-// ------------------------------------------------------------------------------------------------
-// Finish: one wave per trajectory.
-// ------------------------------------------------------------------------------------------------
 struct FinishParams {
   int B, n, m, N, nz, mi, nzp, nc_rows;
   const double* P;  const double* Dz; const double* Phi; const double* Gam;
@@ -176,6 +135,36 @@ struct FinishParams {
   size_t cost_stride;
 };
 
+struct PlantParams {
+  int B, n, m, N;
+  const double* K; const double* A; const double* Bm;
+  const double* v; const double* xbar_pred;   // B x N x m, B x (N+1) x n
+  const double* w;                            // B x n  (stride w_stride between trajectories)
+  size_t w_stride;
+  const int* status;
+  double* x; double* xbar; double* e;         // B x n in/out
+  double* u_out; size_t u_stride;             // may be null
+  double* x_out; size_t x_stride;             // may be null: copy of x+
+  int* sticky;                                // may be null: first non-zero status kept
+};
+
+// Everything the fused closed-loop step needs besides the interior point itself (tz_ipm_kernel with F.on != 0 does
+// tube -> parameter maps -> solve -> recovery / objective -> plant update in one launch; theta, q, h stay in LDS / registers).
+struct FuseParams {
+  int on;
+  int npar, ntheta;
+  TubeParams tube;
+  TzCsr qmap, hmap, parmap;
+  const double* par_lo; const double* par_hi;
+  FinishParams fin;
+  PlantParams plant;
+};
+
+#include "tz_ipm.hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// Finish: one wave per trajectory.
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void tz_finish_kernel(FinishParams p) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int nz = p.nz, n = p.n, m = p.m, N = p.N;
@@ -226,19 +215,6 @@ __global__ __launch_bounds__(64) void tz_finish_kernel(FinishParams p) {
 // Plant / error update: one thread per trajectory.
 //   u = K e + v0 ; x+ = A x + B u + w ; xbar+ = xbar[1] ; e+ = x+ - xbar+
 // ------------------------------------------------------------------------------------------------
-struct PlantParams {
-  int B, n, m, N;
-  const double* K; const double* A; const double* Bm;
-  const double* v; const double* xbar_pred;   // B x N x m, B x (N+1) x n
-  const double* w;                            // B x n  (stride w_stride between trajectories)
-  size_t w_stride;
-  const int* status;
-  double* x; double* xbar; double* e;         // B x n in/out
-  double* u_out; size_t u_stride;             // may be null
-  double* x_out; size_t x_stride;             // may be null: copy of x+
-  int* sticky;                                // may be null: first non-zero status kept
-};
-
 __global__ void tz_plant_kernel(PlantParams p) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= p.B) return;

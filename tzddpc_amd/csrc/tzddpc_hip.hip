@@ -80,7 +80,7 @@ struct tz_problem {
   int max_iter = 40;
   double tol = 1e-10, reg = 1e-12, step_frac = 0.99, cost_scale = 1.0, r0 = 0.0;
   // constants
-  DevBuf<double> P, G, Gt, Gp, act_scale, Dz, Phi, Gam, r1, R2, CK, DK, K, absCK, absKCK, par_lo, par_hi;
+  DevBuf<double> P, G, Gt, Gp, act_scale, Dz, Phi, Gam, r1, R2, CK, DK, K, CKpow, Ttube, par_lo, par_hi;
   DevBuf<int> power, row_of, klist, item_ptr;
   DevBuf<IpmItem> items;
   DevCsr q, h, par;
@@ -88,7 +88,7 @@ struct tz_problem {
   int64_t mfma_gram = 0, mfma_chol = 0, mfma_issued = 0;
   // workspace (capacity Bcap)
   int Bcap = 0;
-  DevBuf<double> theta, tube_ws, qv, hv, x, s, lam, v, xbar, cost, in_x0, in_e0;
+  DevBuf<double> theta, qv, hv, x, s, lam, v, xbar, cost, in_x0, in_e0;
   DevBuf<int> prestatus, status, iters, sticky, prev_status;
   DevBuf<uint8_t> active;
   // closed-loop state / plant (simulate)
@@ -106,6 +106,7 @@ struct tz_problem {
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
   double warm_floor = 1e-4;
   bool warm_enabled = true;
+  bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_FUSE=0: four kernels per step, same arithmetic)
   int maxr = 1, ncg = 1;
   void (*ipm_fn)(IpmParams) = nullptr;
   DevBuf<unsigned long long> prof_buf, work_buf;
@@ -118,7 +119,6 @@ int ensure_workspace(tz_problem* p, int B) {
   TZ_HIP(hipSetDevice(p->device));
   size_t b = (size_t)B;
   TZ_HIP(p->theta.alloc(b * p->ntheta));
-  TZ_HIP(p->tube_ws.alloc(b * (p->pmax + 1) * (3 * p->n + p->m)));
   TZ_HIP(p->qv.alloc(b * p->nz));
   TZ_HIP(p->hv.alloc(b * p->mi));
   TZ_HIP(p->x.alloc(b * p->nz));
@@ -177,6 +177,45 @@ void drain_timing(tz_problem* p) {
   for (int k = 0; k < K_COUNT; ++k) drain_timing_one(p, k);
 }
 
+IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool warm, bool track_prev) {
+  IpmParams ip{};
+  ip.B = B; ip.nz = p->nz; ip.mi = p->mi; ip.nzp = p->nzp; ip.mip = p->mip; ip.Tz = p->Tz; ip.Kc = p->Kc; ip.nquads = p->nquads;
+  ip.P = p->P.p; ip.G = p->G.p; ip.Gt = p->Gt.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p;
+  ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
+  ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
+  ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac;
+  ip.prof = p->prof ? p->prof_buf.p : nullptr;
+  ip.work = p->timing ? p->work_buf.p : nullptr;
+  ip.nklist = p->nklist; ip.nP = p->nP;
+  ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
+  ip.prev_status = warm ? p->prev_status.p : nullptr;
+  ip.status_copy = track_prev ? p->prev_status.p : nullptr;
+  ip.F.on = 0;
+  return ip;
+}
+
+// One closed-loop step of B trajectories in ONE launch (tz_ipm_kernel with F.on): tube, parameter maps, interior point,
+// recovery / objective and plant update; theta, q and h never reach HBM.  Same arithmetic as launch_solve + launch_plant.
+int launch_step_fused(tz_problem* p, int B, double* d_x, double* d_xbar, double* d_e, const double* d_w, size_t w_stride,
+                      const double* d_A, const double* d_Bm, double* d_u, size_t u_stride, double* d_xout, size_t x_stride,
+                      double* d_cost, size_t cost_stride, int* d_status, int* d_sticky, bool warm) {
+  p->lastB = B;
+  Timer tm(p, K_IPM);
+  IpmParams ip = ipm_params(p, B, d_status, p->iters.p, warm, true);
+  FuseParams& F = ip.F;
+  F.on = 1; F.npar = p->npar; F.ntheta = p->ntheta;
+  F.tube = TubeParams{B, p->n, p->m, p->N, p->pmax, p->ntheta, p->CKpow.p, p->Ttube.p, p->power.p, d_xbar, d_e, nullptr, nullptr};
+  F.qmap = p->q.view(); F.hmap = p->h.view(); F.parmap = p->par.view(); F.par_lo = p->par_lo.p; F.par_hi = p->par_hi.p;
+  F.fin = FinishParams{B, p->n, p->m, p->N, p->nz, p->mi, p->nzp, p->nc_rows, p->P.p, p->Dz.p, p->Phi.p, p->Gam.p,
+                       p->r1.p, p->R2.p, p->r0, p->cost_scale, p->row_of.p, p->act_scale.p, d_xbar, nullptr, nullptr, nullptr, nullptr,
+                       d_status, p->v.p, p->xbar.p, d_cost, nullptr, cost_stride};
+  F.plant = PlantParams{B, p->n, p->m, p->N, p->K.p, d_A, d_Bm, nullptr, nullptr, d_w, w_stride, d_status, d_x, d_xbar, d_e,
+                        d_u, u_stride, d_xout, x_stride, d_sticky};
+  hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, p->stream, ip);
+  TZ_HIP(hipGetLastError());
+  return TZ_OK;
+}
+
 // Core launch sequence on device-resident inputs: tube -> affine -> ipm -> finish.
 int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0,
                  double* d_v, double* d_xbar, double* d_cost, int* d_status, int* d_iters, uint8_t* d_active, size_t cost_stride = 1, bool warm = false, bool track_prev = false) {
@@ -184,8 +223,7 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
   p->lastB = B;
   {
     Timer tm(p, K_TUBE);
-    TubeParams tp{B, p->n, p->m, p->N, p->pmax, p->ntheta, p->CK.p, p->DK.p, p->absCK.p, p->absKCK.p, p->power.p,
-                  d_xbar0, d_e0, p->theta.p, p->prestatus.p, p->tube_ws.p, 0};
+    TubeParams tp{B, p->n, p->m, p->N, p->pmax, p->ntheta, p->CKpow.p, p->Ttube.p, p->power.p, d_xbar0, d_e0, p->theta.p, p->prestatus.p};
     hipLaunchKernelGGL(tz_tube_kernel, dim3(B), dim3(64), 0, st, tp);
     AffineParams ap{B, p->ntheta, p->nz, p->mi, p->npar, p->q.view(), p->h.view(), p->par.view(), p->par_lo.p, p->par_hi.p,
                     p->theta.p, p->qv.p, p->hv.p, p->prestatus.p};
@@ -194,7 +232,10 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
   }
   {
     Timer tm(p, K_IPM);
-    IpmParams ip{};
+    IpmParams ip = ipm_params(p, B, d_status, d_iters, warm, track_prev);
+    hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, st, ip);
+  }
+#if 0
     ip.B = B; ip.nz = p->nz; ip.mi = p->mi; ip.nzp = p->nzp; ip.mip = p->mip; ip.Tz = p->Tz; ip.Kc = p->Kc; ip.nquads = p->nquads;
     ip.P = p->P.p; ip.G = p->G.p; ip.Gt = p->Gt.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p;
     ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
@@ -206,8 +247,7 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
     ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
     ip.prev_status = warm ? p->prev_status.p : nullptr;
     ip.status_copy = track_prev ? p->prev_status.p : nullptr;
-    hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, st, ip);
-  }
+#endif
   {
     Timer tm(p, K_FINISH);
     FinishParams fp{B, p->n, p->m, p->N, p->nz, p->mi, p->nzp, p->nc_rows, p->P.p, p->Dz.p, p->Phi.p, p->Gam.p,
@@ -246,7 +286,7 @@ int tz_device_count(int* count) {
 int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (!d || !out) TZ_FAIL(TZ_ERR_INVALID, "null argument");
   if (d->abi_version != TZ_ABI_VERSION) TZ_FAIL(TZ_ERR_INVALID, "abi_version %d != %d", d->abi_version, TZ_ABI_VERSION);
-  if (d->pmax > 64 * TZ_TUBE_SLOTS) TZ_FAIL(TZ_ERR_UNSUPPORTED, "pmax=%d > %d powers of M_K not supported by tz_tube_kernel", d->pmax, 64 * TZ_TUBE_SLOTS);
+  if (d->pmax > TZ_PMAX) TZ_FAIL(TZ_ERR_UNSUPPORTED, "pmax=%d > %d powers of M_K not supported by tz_tube_kernel", d->pmax, TZ_PMAX);
   if (d->n < 1 || d->n > TZ_NMAX || d->m < 1 || d->m > TZ_MMAX) TZ_FAIL(TZ_ERR_UNSUPPORTED, "dim_x must be 1..%d and dim_u 1..%d", TZ_NMAX, TZ_MMAX);
   if (d->N < 1 || d->nz < d->N * d->m || d->mi < 1) TZ_FAIL(TZ_ERR_INVALID, "inconsistent sizes N=%d nz=%d mi=%d", d->N, d->nz, d->mi);
   if (d->nz > 256) TZ_FAIL(TZ_ERR_UNSUPPORTED, "nz=%d > 256 decision variables not supported by tz_ipm_kernel", d->nz);
@@ -352,13 +392,54 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   TZ_HIP(p->r1.upload(d->r1, (size_t)d->n)); TZ_HIP(p->R2.upload(d->R2, (size_t)d->n * d->n));
   TZ_HIP(p->CK.upload(d->CK, (size_t)d->n * d->n)); TZ_HIP(p->DK.upload(d->DK, (size_t)d->n * d->n));
   TZ_HIP(p->K.upload(d->K, (size_t)d->m * d->n));
-  TZ_HIP(p->absCK.upload(d->absCKpow, (size_t)std::max(d->pmax, 1) * d->n * d->n));
-  TZ_HIP(p->absKCK.upload(d->absKCKpow, (size_t)std::max(d->pmax, 1) * d->m * d->n));
+  {
+    // Resolvent of the tube recursion (tz_kernels.hip.h, TubeParams): with X_j = |C_K^j|, U_j = |K C_K^j|,
+    //   R_0 = D_K, R_d = D_K Tx_{d-1};  Tx_d = sum_{j<=d} X_{d-j} R_j;  Tu_d = sum_{j<=d} U_{d-j} R_j;  and C_K^l.
+    const int n = d->n, m = d->m, pm = d->pmax, nm = n + m;
+    std::vector<double> ckp((size_t)(pm + 1) * n * n, 0.0), T((size_t)std::max(pm, 1) * nm * n, 0.0), R((size_t)std::max(pm, 1) * n * n, 0.0);
+    for (int i = 0; i < n; ++i) ckp[(size_t)i * n + i] = 1.0;
+    for (int l = 1; l <= pm; ++l)
+      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+        double a = 0.0;
+        for (int k = 0; k < n; ++k) a += d->CK[i * n + k] * ckp[((size_t)(l - 1) * n + k) * n + j];
+        ckp[((size_t)l * n + i) * n + j] = a;
+      }
+    for (int dd = 0; dd < pm; ++dd) {
+      double* Rd = &R[(size_t)dd * n * n];
+      if (dd == 0) for (int e = 0; e < n * n; ++e) Rd[e] = d->DK[e];
+      else {
+        const double* Tp = &T[(size_t)(dd - 1) * nm * n];      // Tx_{d-1} = first n rows
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+          double a = 0.0;
+          for (int k = 0; k < n; ++k) a += d->DK[i * n + k] * Tp[k * n + j];
+          Rd[i * n + j] = a;
+        }
+      }
+      double* Td = &T[(size_t)dd * nm * n];
+      for (int jj = 0; jj <= dd; ++jj) {
+        const double* X = d->absCKpow + (size_t)(dd - jj) * n * n;
+        const double* U = d->absKCKpow + (size_t)(dd - jj) * m * n;
+        const double* Rj = &R[(size_t)jj * n * n];
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+          double a = 0.0;
+          for (int k = 0; k < n; ++k) a += X[i * n + k] * Rj[k * n + j];
+          Td[i * n + j] += a;
+        }
+        for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) {
+          double a = 0.0;
+          for (int k = 0; k < n; ++k) a += U[i * n + k] * Rj[k * n + j];
+          Td[(n + i) * n + j] += a;
+        }
+      }
+    }
+    TZ_HIP(p->CKpow.upload(ckp.data(), ckp.size()));
+    TZ_HIP(p->Ttube.upload(T.data(), T.size()));
+  }
   TZ_HIP(p->power.upload(d->power, (size_t)d->N));
   TZ_HIP(p->row_of.upload(d->row_of, (size_t)mi));
   TZ_HIP(p->act_scale.upload(d->act_scale, (size_t)mi));
 
-  p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist) * sizeof(double);
+  p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist, p->ntheta) * sizeof(double);
   if (mi > 4 * TZ_THREADS) TZ_FAIL(TZ_ERR_UNSUPPORTED, "mi=%d > %d inequality rows not supported by tz_ipm_kernel", mi, 4 * TZ_THREADS);
   if (p->lds_bytes > 160 * 1024)
     TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
@@ -367,6 +448,8 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
   if (const char* e = getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
   if (const char* e = getenv("TZ_WARM")) { p->warm_enabled = (e[0] != '0'); }
+  if (const char* e = getenv("TZ_FUSE")) { p->fuse_enabled = (e[0] != '0'); }
+  if ((size_t)p->pmax * p->n > (size_t)p->nquads * TZ_QSTR) p->fuse_enabled = false;   // tube scratch borrows the factor storage
   if (const char* e = getenv("TZ_WARM_FLOOR")) { double v = atof(e); if (v > 0) p->warm_floor = v; }
   if (p->prof) TZ_HIP(p->prof_buf.alloc(PH_COUNT));
   TZ_HIP(p->work_buf.alloc(2));
@@ -442,6 +525,11 @@ int tz_mpc_step(tz_problem* p, int32_t B, double* x, double* xbar, double* e, co
   int rc = ensure_workspace(p, B);
   if (rc) return rc;
   const bool warm = p->warm_enabled && p->have_prev && p->prevB == B;
+  if (p->fuse_enabled) {
+    rc = launch_step_fused(p, B, x, xbar, e, w, (size_t)p->n, A_true, B_true, u_out, (size_t)p->m, nullptr, 0, cost, 1, status, nullptr, warm);
+    if (rc == TZ_OK) { p->have_prev = true; p->prevB = B; }
+    return rc;
+  }
   rc = launch_solve(p, B, xbar, e, p->v.p, p->xbar.p, cost, status, p->iters.p, nullptr, 1, warm, true);
   if (rc) return rc;
   p->have_prev = true; p->prevB = B;
@@ -459,6 +547,13 @@ int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, dou
   TZ_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int), p->stream));
   for (int t = 0; t < K; ++t) {
     const bool warm = p->warm_enabled && p->have_prev && p->prevB == B;
+    if (p->fuse_enabled) {
+      rc = launch_step_fused(p, B, x, xbar, e, w + (size_t)t * B * p->n, (size_t)p->n, A_true, B_true, u_out, (size_t)p->m, nullptr, 0,
+                             cost, 1, p->status.p, status, warm);
+      if (rc) return rc;
+      p->have_prev = true; p->prevB = B;
+      continue;
+    }
     rc = launch_solve(p, B, xbar, e, p->v.p, p->xbar.p, cost, p->status.p, p->iters.p, nullptr, 1, warm, true);
     if (rc) return rc;
     p->have_prev = true; p->prevB = B;
@@ -501,6 +596,13 @@ int tz_simulate_batch(tz_problem* p, int32_t B, int32_t T, const double* x0, con
   TZ_HIP(hipMemsetAsync(p->st_e.p, 0, (size_t)B * n * sizeof(double), st));                                        // e = 0   (:70)
   TZ_HIP(hipMemsetAsync(p->sticky.p, 0, (size_t)B * sizeof(int), st));
   for (int t = 0; t < T; ++t) {
+    if (p->fuse_enabled) {
+      rc = launch_step_fused(p, B, p->st_x.p, p->st_xbar.p, p->st_e.p, dnoise + (size_t)t * n, (size_t)T * n, dA, dB,
+                             du + (size_t)t * m, (size_t)T * m, dx + (size_t)(t + 1) * n, (size_t)(T + 1) * n,
+                             dcost + t, (size_t)T, p->status.p, p->sticky.p, p->warm_enabled && t > 0);
+      if (rc) return rc;
+      continue;
+    }
     rc = launch_solve(p, B, p->st_xbar.p, p->st_e.p, p->v.p, p->xbar.p, dcost + t, p->status.p, p->iters.p, nullptr, (size_t)T, p->warm_enabled && t > 0, true);
     if (rc) return rc;
     rc = launch_plant(p, B, dA, dB, dnoise + (size_t)t * n, (size_t)T * n, p->v.p, p->xbar.p, p->status.p,
