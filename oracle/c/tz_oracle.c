@@ -36,6 +36,8 @@ typedef struct tzo_desc {
   const double *CK, *DK, *K;      /* n x n, n x n, m x n */
   int32_t pmax; const double *absCK, *absKCK; const int32_t *power;
   int32_t max_iter; double tol, reg, step_frac;
+  double warm_floor, warm_gain;   /* closed-loop warm start (tzo_simulate_batch): see ipm() */
+  double mu_tol;                  /* complementarity target (<= tol) */
 } tzo_desc;
 
 typedef struct {
@@ -170,11 +172,19 @@ static double max_step(int n, const double* v, const double* dv) {
 }
 
 /* status: 0 solved, 1 max_iter, 2 numerical, 3 infeasible */
-static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const double* h, double* x, double* s, double* lam, int* iters, double* wk) {
+/* warm != 0: x / lam hold the previous closed-loop step's solution of this trajectory; the slacks are re-derived for the
+ * new h and (s, lam) pushed into the cone by max(warm_floor, warm_gain * largest violation of the new rows). */
+static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const double* h, double* x, double* s, double* lam, int* iters, double* wk, int warm) {
   int nz = S->nz, mi = S->mi;
   double* H = wk; double* GW = H + nz * nz;
   double* w = GW + mi * nz; double* rd = w + mi; double* rp = rd + nz; double* r1 = rp + mi;
   double* dx = r1 + nz; double* ds = dx + nz; double* dl = ds + mi; double* t1 = dl + mi; double* gx = t1 + mi; double* gdx = gx + mi; double* rc = gdx + mi;
+  if (warm) {
+    double viol = 0;
+    for (int r = 0; r < mi; ++r) { double a = 0; for (int c = 0; c < nz; ++c) a += S->G[r * nz + c] * x[c]; gx[r] = a; viol = fmax(viol, a - h[r]); }
+    double sig = fmax(d->warm_floor, d->warm_gain * viol);
+    for (int r = 0; r < mi; ++r) { s[r] = fmax(h[r] - gx[r], sig); lam[r] = fmax(lam[r], sig); }
+  } else {
   for (int r = 0; r < mi; ++r) w[r] = 1.0;
   form_H(S, w, d->reg, H, GW);
   if (!cholesky(nz, H)) return 2;
@@ -184,6 +194,7 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
   for (int r = 0; r < mi; ++r) { double a = 0; for (int c = 0; c < nz; ++c) a += S->G[r * nz + c] * x[c]; gx[r] = a; rmin = fmin(rmin, h[r] - a); }
   double shift = rmin <= 1e-8 ? fmax(0.0, 1.0 - rmin) : 0.0;
   for (int r = 0; r < mi; ++r) { s[r] = h[r] - gx[r] + shift; lam[r] = 1.0; }
+  }
   double scd = 0, scp = 0;
   for (int c = 0; c < nz; ++c) scd = fmax(scd, fabs(q[c]));
   for (int r = 0; r < mi; ++r) scp = fmax(scp, fabs(h[r]));
@@ -200,8 +211,8 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
     for (int r = 0; r < mi; ++r) { rp[r] = gx[r] + s[r] - h[r]; nrp = fmax(nrp, fabs(rp[r])); mu += s[r] * lam[r]; }
     mu /= mi; nrd /= scd; nrp /= scp;
     *iters = it;
-    if (nrd <= d->tol && nrp <= d->tol && mu <= d->tol) return 0;
-    if (mu <= 1e-3 * d->tol) return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 3;
+    if (nrd <= d->tol && nrp <= d->tol && mu <= d->mu_tol) return 0;
+    if (mu <= 1e-3 * d->mu_tol) return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 3;
     if (!(mu == mu) || !(nrd == nrd) || mu > 1e200) return 2;
     for (int r = 0; r < mi; ++r) w[r] = lam[r] / s[r];
     form_H(S, w, d->reg, H, GW);
@@ -236,7 +247,7 @@ static size_t work_doubles(const tzo_desc* d, const setup_t* S) {
 }
 
 static void solve_one(const tzo_desc* d, const setup_t* S, const double* xbar0, const double* e0,
-                      double* v, double* xbar, double* cost, int32_t* status, int32_t* iters, uint8_t* active, double* wk) {
+                      double* v, double* xbar, double* cost, int32_t* status, int32_t* iters, uint8_t* active, double* wk, int warm) {
   int nz = S->nz, mi = S->mi, n = d->n, m = d->m, N = d->N, nt = d->ntheta;
   double* th = wk; double* q = th + nt; double* h = q + nz; double* x = h + mi; double* s = x + nz; double* lam = s + mi;
   double* tws = lam + mi; double* iw = tws + (size_t)(d->pmax + 2) * (3 * n + m);
@@ -254,7 +265,7 @@ static void solve_one(const tzo_desc* d, const setup_t* S, const double* xbar0, 
       for (int t = 0; t < nt; ++t) a += M[r * nt + t] * th[t];
       h[k] = S->E[k] * S->sgn[k] * a;
     }
-    st = ipm(d, S, q, h, x, s, lam, &it, iw);
+    st = ipm(d, S, q, h, x, s, lam, &it, iw, warm);
   } else { for (int c = 0; c < nz; ++c) x[c] = 0; }
   *status = st; if (iters) *iters = it;
   double obj = 0;
@@ -290,7 +301,7 @@ int tzo_solve_batch(const tzo_desc* d, int B, const double* xbar0, const double*
 #endif
     for (int b = 0; b < B; ++b)
       solve_one(d, S, xbar0 + (size_t)b * n, e0 + (size_t)b * n, v + (size_t)b * N * m, xbar + (size_t)b * (N + 1) * n,
-                cost + b, status + b, iters ? iters + b : NULL, active ? active + (size_t)b * d->nc : NULL, wk);
+                cost + b, status + b, iters ? iters + b : NULL, active ? active + (size_t)b * d->nc : NULL, wk, 0);
     free(wk);
   }
   free_setup(S);
@@ -316,11 +327,12 @@ int tzo_simulate_batch(const tzo_desc* d, int B, int T, const double* x0, const 
 #pragma omp for schedule(dynamic, 4)
 #endif
     for (int b = 0; b < B; ++b) {
-      int32_t sticky = 0;
+      int32_t sticky = 0; int prev_ok = 0;
       for (int i = 0; i < n; ++i) { x[i] = x0[(size_t)b * n + i]; xbar[i] = x[i]; e[i] = 0; x_traj[((size_t)b * (T + 1)) * n + i] = x[i]; }
       for (int t = 0; t < T; ++t) {
         int32_t st, it; double c;
-        solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk);
+        solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk, prev_ok);   /* x / s / lam of the previous step live on in wk */
+        prev_ok = (st == 0) && d->warm_floor > 0;
         if (!sticky && st) sticky = st;
         if (cost) cost[(size_t)b * T + t] = c;
         for (int j = 0; j < m; ++j) { double a = v[j]; for (int i = 0; i < n; ++i) a += d->K[j * n + i] * e[i]; u[j] = a; u_traj[((size_t)b * T + t) * m + j] = a; }

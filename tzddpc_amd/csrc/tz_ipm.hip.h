@@ -36,7 +36,10 @@ struct IpmParams {
   const int* prev_status;   // warm start gate: status of the previous closed-loop step (may alias nothing else); null = cold
   int* status_copy;         // optional second destination of the status (library-owned copy for the next step)
   int max_iter; double tol, reg, step_frac;
+  double mu_tol;              // complementarity target (<= tol): the distance to the solution of a degenerate problem goes like sqrt(mu)
   int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
+  double warm_gain, warm_cold;   // warm point pushed into the cone by max(warm_floor, warm_gain * violation); violation > warm_cold: cold start
+  double sf_gain, sf_cap;        // fraction to the boundary = min(sf_cap, max(step_frac, 1 - sf_gain * mu))
   unsigned long long* work;   // [0] += factorisations, [1] += solved trajectories (bench.py roofline accounting); may be null
   unsigned long long* prof;   // TZ_PROF=1: per-phase cycle sums of workgroup 0 (diagnostic; no output depends on it)
   FuseParams F;               // F.on != 0: whole closed-loop step in this launch (q, h, prestatus above are then unused)
@@ -523,19 +526,31 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   };
 
   bool okf = true;
-  const bool warm = !skip && p.warm != 0 && p.prev_status != nullptr && p.prev_status[b] == 0;     // previous step of this trajectory was solved: start from it
+  bool warm = !skip && p.warm != 0 && p.prev_status != nullptr && p.prev_status[b] == 0;     // previous step of this trajectory was solved: start from it
   double scq = 0, sch = 0;
   if (!skip) {
   if (warm) {
     // ---- warm start: previous (x, lambda) of this trajectory, slacks re-derived for the new h and pushed into the cone
+    // by at least the amount the old point violates the new rows; a point that is too far outside starts cold instead
     for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + c];
     __syncthreads();
     tz_gemv_G<MAXR>(p, xv, gx_);
-    TZ_ROWS(k, r) {
-      s_[k] = fmax(h_[k] - gx_[k], p.warm_floor);
-      l_[k] = fmax(p.lam[(size_t)b * mi + r], p.warm_floor);
+    double viol = 0.0, zv1 = 0.0, zv2 = 0.0;
+    TZ_ROWS(k, r) viol = fmax(viol, gx_[k] - h_[k]);
+    tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, zv1, zv2, red);
+    if (p.warm_cold > 0.0 && viol > p.warm_cold) {
+      warm = false;
+      for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
+      __syncthreads();
+    } else {
+      const double sig = fmax(p.warm_floor, p.warm_gain * viol);
+      TZ_ROWS(k, r) {
+        s_[k] = fmax(h_[k] - gx_[k], sig);
+        l_[k] = fmax(p.lam[(size_t)b * mi + r], sig);
+      }
     }
-  } else {
+  }
+  if (!warm) {
     // ---- cold start: (P + G'G + reg) x = -q + G'h, then shift the slacks into the cone
     tz_form_H(p, Hq, vin, kl);
     __syncthreads();
@@ -575,15 +590,15 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(nrd, nrp, sl, red);
     const double mu = sl / mi;
     nrd /= sc_d; nrp /= sc_p;
-    if ((nrd <= p.tol && nrp <= p.tol && mu <= p.tol) || mu <= 1e-3 * p.tol) {
+    if ((nrd <= p.tol && nrp <= p.tol && mu <= p.mu_tol) || mu <= 1e-3 * p.mu_tol) {
       exact_rd();
       double e1 = 0, e2 = 0, e3 = 0;
       for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
       tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(e1, e2, e3, red);
       nrd = e1 / sc_d;
       TZ_STAMP(PH_GEMVT);
-      if (nrd <= p.tol && nrp <= p.tol && mu <= p.tol) { status = 0; break; }
-      if (mu <= 1e-3 * p.tol) { status = (nrd <= 1e3 * p.tol && nrp <= 1e3 * p.tol) ? 0 : 3; break; }
+      if (nrd <= p.tol && nrp <= p.tol && mu <= p.mu_tol) { status = 0; break; }
+      if (mu <= 1e-3 * p.mu_tol) { status = (nrd <= 1e3 * p.tol && nrp <= 1e3 * p.tol) ? 0 : 3; break; }
     }
     if (!(mu == mu) || !(nrd == nrd) || mu > 1e200) { status = 2; break; }
     // Newton matrix.  is = 1/s, il = 1/lambda are the only two divisions per row and iteration.
@@ -654,7 +669,8 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     }
     tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(ms, ml, z3, red);
     const double mm = fmax(ms, ml);
-    const double alpha = (mm * 1.0 > p.step_frac) ? p.step_frac / mm : 1.0;      // min(1, step_frac * min_i(-v_i/dv_i))
+    const double sfr = (p.sf_gain > 0.0) ? fmin(p.sf_cap, fmax(p.step_frac, 1.0 - p.sf_gain * mu)) : p.step_frac;
+    const double alpha = (mm * 1.0 > sfr) ? sfr / mm : 1.0;      // min(1, sfr * min_i(-v_i/dv_i))
     for (int c = t; c < nz; c += TZ_THREADS) { xv[c] += alpha * dxv[c]; rdv[c] *= (1.0 - alpha); }
     TZ_ROWS(k, r) { s_[k] += alpha * ds_[k]; l_[k] += alpha * dl_[k]; gx_[k] += alpha * g_[k]; }
     __syncthreads();

@@ -104,7 +104,7 @@ struct tz_problem {
   int lastB = 0;
   bool prof = false;
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
-  double warm_floor = 1e-4;
+  double warm_floor = 1e-5, warm_gain = 1.0, warm_cold = 0.0, sf_gain = 0.0, sf_cap = 1.0, mu_factor = 0.1;
   bool warm_enabled = true;
   bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_FUSE=0: four kernels per step, same arithmetic)
   int maxr = 1, ncg = 1;
@@ -183,11 +183,12 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.P = p->P.p; ip.G = p->G.p; ip.Gt = p->Gt.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p;
   ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
   ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
-  ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac;
+  ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac; ip.mu_tol = p->tol * p->mu_factor;
   ip.prof = p->prof ? p->prof_buf.p : nullptr;
   ip.work = p->timing ? p->work_buf.p : nullptr;
   ip.nklist = p->nklist; ip.nP = p->nP;
   ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
+  ip.warm_gain = p->warm_gain; ip.warm_cold = p->warm_cold; ip.sf_gain = p->sf_gain; ip.sf_cap = p->sf_cap;
   ip.prev_status = warm ? p->prev_status.p : nullptr;
   ip.status_copy = track_prev ? p->prev_status.p : nullptr;
   ip.F.on = 0;
@@ -235,19 +236,6 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
     IpmParams ip = ipm_params(p, B, d_status, d_iters, warm, track_prev);
     hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, st, ip);
   }
-#if 0
-    ip.B = B; ip.nz = p->nz; ip.mi = p->mi; ip.nzp = p->nzp; ip.mip = p->mip; ip.Tz = p->Tz; ip.Kc = p->Kc; ip.nquads = p->nquads;
-    ip.P = p->P.p; ip.G = p->G.p; ip.Gt = p->Gt.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p;
-    ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
-    ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
-    ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac;
-    ip.prof = p->prof ? p->prof_buf.p : nullptr;
-    ip.work = p->timing ? p->work_buf.p : nullptr;
-    ip.nklist = p->nklist; ip.nP = p->nP;
-    ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
-    ip.prev_status = warm ? p->prev_status.p : nullptr;
-    ip.status_copy = track_prev ? p->prev_status.p : nullptr;
-#endif
   {
     Timer tm(p, K_FINISH);
     FinishParams fp{B, p->n, p->m, p->N, p->nz, p->mi, p->nzp, p->nc_rows, p->P.p, p->Dz.p, p->Phi.p, p->Gam.p,
@@ -451,6 +439,11 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (const char* e = getenv("TZ_FUSE")) { p->fuse_enabled = (e[0] != '0'); }
   if ((size_t)p->pmax * p->n > (size_t)p->nquads * TZ_QSTR) p->fuse_enabled = false;   // tube scratch borrows the factor storage
   if (const char* e = getenv("TZ_WARM_FLOOR")) { double v = atof(e); if (v > 0) p->warm_floor = v; }
+  if (const char* e = getenv("TZ_WARM_GAIN")) p->warm_gain = atof(e);
+  if (const char* e = getenv("TZ_WARM_COLD")) p->warm_cold = atof(e);
+  if (const char* e = getenv("TZ_SF_GAIN")) p->sf_gain = atof(e);
+  if (const char* e = getenv("TZ_SF_CAP")) p->sf_cap = atof(e);
+  if (const char* e = getenv("TZ_MU_FACTOR")) p->mu_factor = atof(e);
   if (p->prof) TZ_HIP(p->prof_buf.alloc(PH_COUNT));
   TZ_HIP(p->work_buf.alloc(2));
   TZ_HIP(hipMemset(p->work_buf.p, 0, 2 * sizeof(unsigned long long)));
@@ -689,6 +682,13 @@ int tz_debug_fetch(tz_problem* p, int32_t b, int what, double* out, int32_t capa
       if (capacity < PH_COUNT) TZ_FAIL(TZ_ERR_INVALID, "capacity too small");
       for (int i = 0; i < PH_COUNT; ++i) out[i] = (double)h[i];
       return PH_COUNT;
+    }
+    case 7: {   // interior-point iterations of every trajectory of the last launch (b ignored)
+      if (capacity < p->lastB) TZ_FAIL(TZ_ERR_INVALID, "capacity %d < %d", capacity, p->lastB);
+      std::vector<int> h((size_t)p->lastB);
+      TZ_HIP(hipMemcpy(h.data(), p->iters.p, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+      for (int i = 0; i < p->lastB; ++i) out[i] = (double)h[i];
+      return p->lastB;
     }
     default: TZ_FAIL(TZ_ERR_INVALID, "unknown debug item %d", what);
   }

@@ -149,7 +149,7 @@ class Problem:
 
     def __init__(self, device: int, *, n, m, N, P, G, q0, Qt, h0, Ht, par0, Part, par_lo, par_hi, cost_scale, r0, r1, R2,
                  Dz, Phi, Gam, nc_rows, row_of, act_scale, CK, DK, K, pmax, absCKpow, absKCKpow, power,
-                 max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99):
+                 max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.9999):
         L = lib()
         keep = []
         d = ProblemDesc()
@@ -251,8 +251,14 @@ class Problem:
         return dict(mfma_gram_per_iter=a.value, mfma_chol_per_iter=b.value, mfma_issued_per_iter=i.value,
                     lds_bytes=c.value, patch_bytes=d.value)
 
+    def last_iterations(self, B: int) -> np.ndarray:
+        """Interior-point iterations of each trajectory in the last launch (diagnostic)."""
+        out = np.empty(int(B))
+        n = check(lib().tz_debug_fetch(self._h, 0, 7, out.ctypes.data_as(C.c_void_p), int(B)), "tz_debug_fetch")
+        return out[:n].astype(np.int64)
+
     def debug_fetch(self, b: int, what: int) -> np.ndarray:
-        cap = max(self.nz, self.mi, self.ntheta)
+        cap = max(self.nz, self.mi, self.ntheta, 16)
         out = np.empty(cap)
         n = check(lib().tz_debug_fetch(self._h, int(b), int(what), out.ctypes.data_as(C.c_void_p), cap), "tz_debug_fetch")
         return out[:n].copy()
