@@ -4,7 +4,7 @@ os.environ["TZ_PROF"] = "1"
 sys.path.insert(0, ".")
 import torch
 from tests import common
-names = ["formH", "chol", "solve", "gemvT", "gemvG", "elem", "total", "iters", "ch_upd", "ch_diag", "ch_panel", "ch_bar", "prologue", "epilogue"]
+names = ["formH", "chol", "solve", "gemvT", "gemvG", "elem", "total", "iters", "ch_upd", "ch_diag", "ch_panel", "ch_bar", "prologue", "epilogue", "gram_loop", "gram_red", "gram_bar", "gram_rmw"]
 case = sys.argv[1] if len(sys.argv) > 1 else "di_n20"
 ctl, (A, B, zon) = common.gpu_controller(case)
 nat = ctl._native

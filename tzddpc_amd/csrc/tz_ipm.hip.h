@@ -29,6 +29,7 @@ struct IpmParams {
   const IpmItem* items;  // Gram work items, grouped per wave
   const int* item_ptr;   // TZ_NWAVES + 1
   const int* klist;
+  const int* smask;      // ksplit: per super-step (16 rows of G) bit J set when tile column J has a non-zero; smask[S] = 0
   const double* q; const double* h;
   const int* prestatus;
   double* x; double* s; double* lam;
@@ -37,6 +38,7 @@ struct IpmParams {
   int* status_copy;         // optional second destination of the status (library-owned copy for the next step)
   int max_iter; double tol, reg, step_frac;
   double mu_tol;              // complementarity target (<= tol): the distance to the solution of a degenerate problem goes like sqrt(mu)
+  int ksplit;                 // Gram by tz_form_H_ksplit (Tz <= TZ_KS_TZ) instead of the item plan
   int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
   double warm_gain, warm_cold;   // warm point pushed into the cone by max(warm_floor, warm_gain * violation); violation > warm_cold: cold start
   double sf_gain, sf_cap;        // fraction to the boundary = min(sf_cap, max(step_frac, 1 - sf_gain * mu))
@@ -45,7 +47,7 @@ struct IpmParams {
   FuseParams F;               // F.on != 0: whole closed-loop step in this launch (q, h, prestatus above are then unused)
 };
 
-enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_CH_UPD = 8, PH_CH_DIAG = 9, PH_CH_PANEL = 10, PH_CH_BAR = 11, PH_PROLOGUE = 12, PH_EPILOGUE = 13, PH_COUNT = 14 };
+enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_CH_UPD = 8, PH_CH_DIAG = 9, PH_CH_PANEL = 10, PH_CH_BAR = 11, PH_PROLOGUE = 12, PH_EPILOGUE = 13, PH_GRAM_LOOP = 14, PH_GRAM_RED = 15, PH_GRAM_BAR = 16, PH_GRAM_RMW = 17, PH_COUNT = 18 };
 
 __device__ inline int tz_qprefix(int I) {   // number of quads in tile rows < I (row I has (I>>2)+1 quads)
   int a = I >> 2, b = I & 3;
@@ -227,6 +229,125 @@ __device__ inline void tz_form_H(const IpmParams& p, double* Hq, const double* w
       }
     }
   }
+}
+
+// Gram matrix for small problems (Tz <= TZ_KS_TZ tile columns, i.e. nz <= 40).
+// The four blocks of v_mfma_f64_4x4x4 take four DIFFERENT patch rows (blk = patch row 4s + blk of "super-step" s) of the
+// SAME output tile (I, J): lane (k, blk, ij) loads element [k][ij] of every tile of its patch row once -- 64 distinct
+// doubles per load instruction, nothing is fetched twice into registers (the L1 -> register path, 64 B/clk per CU, is what
+// bounds every pass over G) -- and that one value is the A operand (times w) of the tiles in row I and the B operand of
+// the tiles in column J.  One MFMA per (super-step, tile); tiles whose column I or J is entirely zero in the super-step
+// are skipped (wave-uniform bit tests of a host-built mask).  The waves split the work 2 x 2: wave>>1 picks the tile-row
+// range [R0, R1), wave&1 the even / odd super-steps; the partial sums are folded over blk with DPP row rotations and the
+// two halves added through LDS in a fixed order (deterministic).
+#define TZ_KS_TZ 10
+#ifndef TZ_GRAM_MASK
+#define TZ_GRAM_MASK 1
+#endif
+__device__ inline double tz_sel4(int blk, double v0, double v1, double v2, double v3) {
+  const double a = (blk & 1) ? v1 : v0, b = (blk & 1) ? v3 : v2;
+  return (blk & 2) ? b : a;
+}
+struct TzGStage { double v[TZ_KS_TZ]; double w; int m; };
+
+template <int N>
+__device__ inline double tz_row_ror(double v) {                          // value of lane ((lane & 15) - N) mod 16 of the same row of 16
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  constexpr int ctrl = 0x120 + N;
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, ctrl, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), ctrl, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+template <int R0, int R1>
+__device__ inline void tz_gram_rows(const IpmParams& p, double* Hq, const double* Pq, const double* wv, const int* sm, const int h, unsigned long long* pacc) {
+  unsigned long long tq0 = pacc ? __builtin_amdgcn_s_memtime() : 0;
+  const int lane = threadIdx.x & 63;
+  const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
+  const int Tz = p.Tz, Kc = p.Kc, S = (Kc + 3) >> 2;
+  const unsigned rowbytes = (unsigned)(Tz + 1) * 128u;
+  const char* gp = (const char*)p.Gp + (unsigned)(4 * k + ij) * 8u;
+  double acc[R1 - R0][R1];
+#pragma unroll
+  for (int a = 0; a < R1 - R0; ++a)
+#pragma unroll
+    for (int J = 0; J < R1; ++J) acc[a][J] = 0.0;
+  auto load = [&](int s, TzGStage& st) {
+    int kc = 4 * s + blk; kc = (kc < Kc) ? kc : Kc;                      // patch row Kc is all zero, wv[4 Kc + k] = 0
+#if TZ_GRAM_MASK
+    st.m = sm[s < S ? s : S];                                            // LDS copy of smask, smask[S] = 0 (made scalar at its use)
+#else
+    st.m = 0x3ff; (void)sm;
+#endif
+    st.w = wv[4 * kc + k];
+    const char* prow = gp + (size_t)kc * rowbytes;
+#pragma unroll
+    for (int J = 0; J < R1; ++J) st.v[J] = tz_ld_pinned((const double*)(prow + (unsigned)(J < Tz ? J : Tz) * 128u));   // tile Tz is zero
+  };
+  auto mma = [&](const TzGStage& st) {
+#if TZ_GRAM_MASK
+    const int m = __builtin_amdgcn_readfirstlane(st.m);
+#else
+    const int m = 0x3ff;
+#endif
+#pragma unroll
+    for (int I = R0; I < R1; ++I) {
+      if ((m >> I) & 1) {
+        const double a = st.v[I] * st.w;
+#pragma unroll
+        for (int J = 0; J <= I; ++J)
+          if ((m >> J) & 1) acc[I - R0][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, st.v[J], acc[I - R0][J], 0, 0, 0);
+      }
+    }
+  };
+  TzGStage s0, s1;
+  load(h, s0);
+  for (int s = h; s < S; s += 4) {
+    load(s + 2, s1); mma(s0);
+    load(s + 4, s0); mma(s1);
+  }
+  if (pacc) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); pacc[PH_GRAM_LOOP] += t1 - tq0; tq0 = t1; }
+  // fold the four patch rows (blk) of every tile with two row rotations (every lane of a row of 16 then holds the tile sum),
+  // then store quad by quad: lane (i, blk, j) keeps tile J = 4q + blk, so each quad is ONE full-wave, conflict-free LDS
+  // access: H(4I + i, 4(4q + blk) + j).  Tiles right of the diagonal inside the diagonal quad are never read.
+  const int i = lane >> 4, j = lane & 3;
+#pragma unroll
+  for (int a = 0; a < R1 - R0; ++a)
+#pragma unroll
+    for (int J = 0; J < R1; ++J)
+      if (J <= a + R0) { double v = acc[a][J]; v += tz_row_ror<4>(v); v += tz_row_ror<8>(v); acc[a][J] = v; }
+  for (int hh = 0; hh < 2; ++hh) {
+    if (h == hh) {
+#pragma unroll
+      for (int I = R0; I < R1; ++I) {
+        if (I >= Tz) continue;
+#pragma unroll
+        for (int q = 0; q <= (I >> 2); ++q) {
+          const double v0 = acc[I - R0][4 * q];
+          const double v1 = (4 * q + 1 <= I) ? acc[I - R0][(4 * q + 1 <= I) ? 4 * q + 1 : 0] : 0.0;
+          const double v2 = (4 * q + 2 <= I) ? acc[I - R0][(4 * q + 2 <= I) ? 4 * q + 2 : 0] : 0.0;
+          const double v3 = (4 * q + 3 <= I) ? acc[I - R0][(4 * q + 3 <= I) ? 4 * q + 3 : 0] : 0.0;
+          const int idx = (tz_qprefix(I) + q) * TZ_QSTR + TZ_QROW * i + 4 * blk + j;
+          Hq[idx] = tz_sel4(blk, v0, v1, v2, v3) + ((hh == 0) ? Pq[idx] : Hq[idx]);
+        }
+      }
+    }
+    if (pacc) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); pacc[hh == 0 ? PH_GRAM_RED : PH_GRAM_RMW] += t1 - tq0; tq0 = t1; }
+    if (hh == 0) __syncthreads();
+    if (pacc && hh == 0) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); pacc[PH_GRAM_BAR] += t1 - tq0; tq0 = t1; }
+  }
+}
+
+__device__ inline void tz_form_H_ksplit(const IpmParams& p, double* Hq, const double* Pq, const double* wv, const int* sm, unsigned long long* pacc) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = wave >> 1, h = wave & 1;
+  if (p.Tz > 7) { if (g == 0) tz_gram_rows<0, 7>(p, Hq, Pq, wv, sm, h, pacc); else tz_gram_rows<7, 10>(p, Hq, Pq, wv, sm, h, pacc); }
+  else          { if (g == 0) tz_gram_rows<0, 5>(p, Hq, Pq, wv, sm, h, pacc); else tz_gram_rows<5, 7>(p, Hq, Pq, wv, sm, h, pacc); }
+}
+
+__device__ inline void tz_gram(const IpmParams& p, double* Hq, const double* Pq, const double* wv, const int* kl, unsigned long long* pacc = nullptr) {
+  if (p.ksplit) tz_form_H_ksplit(p, Hq, Pq, wv, kl, pacc);     // kl holds the super-step masks in this mode
+  else tz_form_H(p, Hq, wv, kl);
 }
 
 // sqrt(d) and 1/sqrt(d) from v_rsq_f64 + two coupled Newton steps (deterministic, ~1 ulp; no f64 divide / sqrt sequences)
@@ -445,15 +566,15 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
 }
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
-__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta) {
-  return (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 10 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta;
+__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit) {
+  return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 10 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta;
 }
 
 template <int MAXR, int NCG>
 __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmParams p) {
   const bool PROF = p.prof != nullptr && blockIdx.x == 0;
   unsigned long long tprev = 0, tstart = 0;
-  unsigned long long acc_ph[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long acc_ph[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define TZ_STAMP(ph) do { if (PROF) { unsigned long long _t = __builtin_amdgcn_s_memtime(); acc_ph[ph] += _t - tprev; tprev = _t; } } while (0)
   if (PROF) { tprev = __builtin_amdgcn_s_memtime(); tstart = tprev; }
   extern __shared__ double lds[];
@@ -482,6 +603,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   int* flag = (int*)(red + 16);
   int* kl = (int*)(red + 18);
   double* thl = red + 18 + (p.nklist + 1) / 2;      // theta of this trajectory (fused step only)
+  double* Pq = thl + p.F.ntheta;                    // ksplit: P + reg I in the quad layout of Hq (lower tiles)
 
   // rows owned by this thread
   double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR], w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR], is_[MAXR], il_[MAXR];
@@ -502,7 +624,19 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   } else
   for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? p.q[(size_t)b * nz + c] : 0.0; xv[c] = 0.0; }
   for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the start point
-  for (int i = t; i < p.nklist; i += TZ_THREADS) kl[i] = p.klist[i];
+  if (p.ksplit) {
+    for (int i = t; i <= ((p.Kc + 3) >> 2); i += TZ_THREADS) kl[i] = p.smask[i];
+    for (int e = t; e < p.nquads * 64; e += TZ_THREADS) {                // every entry of every quad (padding tiles: 0)
+      const int qd = e >> 6;
+      int I = 0;
+      while (tz_qprefix(I + 1) <= qd) ++I;
+      const int r = 4 * I + ((e >> 4) & 3), c = 4 * (4 * (qd - tz_qprefix(I)) + ((e >> 2) & 3)) + (e & 3);
+      double v = (c < nzp) ? p.P[(size_t)r * nzp + c] : 0.0;
+      if (r == c) v = (r < nz) ? v + p.reg : 1.0;
+      Pq[qd * TZ_QSTR + TZ_QROW * ((e >> 4) & 3) + (e & 15)] = v;
+    }
+  }
+  else for (int i = t; i < p.nklist; i += TZ_THREADS) kl[i] = p.klist[i];
 #pragma unroll
   for (int k = 0; k < MAXR; ++k) { s_[k] = 1.0; l_[k] = 0.0; h_[k] = 0.0; gx_[k] = 0.0; w_[k] = 0.0; rp_[k] = 0.0; ds_[k] = 0.0; dl_[k] = 0.0; g_[k] = 0.0; is_[k] = 1.0; il_[k] = 1.0; }
   if (fused) { TZ_ROWS(k, r) { h_[k] = csr_row(F.hmap, r, thl); l_[k] = 1.0; } }
@@ -552,7 +686,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   }
   if (!warm) {
     // ---- cold start: (P + G'G + reg) x = -q + G'h, then shift the slacks into the cone
-    tz_form_H(p, Hq, vin, kl);
+    tz_gram(p, Hq, Pq, vin, kl);
     __syncthreads();
     TZ_ROWS(k, r) vin[r] = h_[k];
     __syncthreads();
@@ -605,7 +739,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     TZ_ROWS(k, r) { is_[k] = 1.0 / s_[k]; il_[k] = 1.0 / l_[k]; w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
     __syncthreads();
     TZ_STAMP(PH_ELEM);
-    tz_form_H(p, Hq, vin, kl);
+    tz_gram(p, Hq, Pq, vin, kl, (PROF && t == 0) ? acc_ph : nullptr);
     __syncthreads();
     TZ_STAMP(PH_FORM);
     if (!tz_cholesky(p, Hq, dinv, flag, (PROF && t == 0) ? acc_ph : nullptr)) { status = 2; break; }

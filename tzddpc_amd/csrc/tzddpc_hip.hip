@@ -81,7 +81,7 @@ struct tz_problem {
   double tol = 1e-10, reg = 1e-12, step_frac = 0.99, cost_scale = 1.0, r0 = 0.0;
   // constants
   DevBuf<double> P, G, Gt, Gp, act_scale, Dz, Phi, Gam, r1, R2, CK, DK, K, CKpow, Ttube, par_lo, par_hi;
-  DevBuf<int> power, row_of, klist, item_ptr;
+  DevBuf<int> power, row_of, klist, item_ptr, smask;
   DevBuf<IpmItem> items;
   DevCsr q, h, par;
   size_t lds_bytes = 0;
@@ -106,6 +106,7 @@ struct tz_problem {
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
   double warm_floor = 1e-5, warm_gain = 1.0, warm_cold = 0.0, sf_gain = 0.0, sf_cap = 1.0, mu_factor = 0.1;
   bool warm_enabled = true;
+  bool ksplit = false;         // Gram by k-split (Tz <= TZ_KS_TZ; TZ_KSPLIT=0 keeps the item plan)
   bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_FUSE=0: four kernels per step, same arithmetic)
   int maxr = 1, ncg = 1;
   void (*ipm_fn)(IpmParams) = nullptr;
@@ -180,13 +181,13 @@ void drain_timing(tz_problem* p) {
 IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool warm, bool track_prev) {
   IpmParams ip{};
   ip.B = B; ip.nz = p->nz; ip.mi = p->mi; ip.nzp = p->nzp; ip.mip = p->mip; ip.Tz = p->Tz; ip.Kc = p->Kc; ip.nquads = p->nquads;
-  ip.P = p->P.p; ip.G = p->G.p; ip.Gt = p->Gt.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p;
+  ip.P = p->P.p; ip.G = p->G.p; ip.Gt = p->Gt.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p; ip.smask = p->smask.p;
   ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
   ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
   ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac; ip.mu_tol = p->tol * p->mu_factor;
   ip.prof = p->prof ? p->prof_buf.p : nullptr;
   ip.work = p->timing ? p->work_buf.p : nullptr;
-  ip.nklist = p->nklist; ip.nP = p->nP;
+  ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0;
   ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
   ip.warm_gain = p->warm_gain; ip.warm_cold = p->warm_cold; ip.sf_gain = p->sf_gain; ip.sf_cap = p->sf_cap;
   ip.prev_status = warm ? p->prev_status.p : nullptr;
@@ -369,8 +370,14 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   p->mfma_issued += p->mfma_chol;
 
   TZ_HIP(p->P.upload(P)); TZ_HIP(p->G.upload(G)); TZ_HIP(p->Gt.upload(Gt)); TZ_HIP(p->Gp.upload(Gp));
+  {
+    const int S = (Kc + 3) / 4;
+    std::vector<int> sm((size_t)S + 1, 0);
+    for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) if (G[(size_t)r * nzp + c] != 0.0) sm[r >> 4] |= 1 << (c >> 2);
+    TZ_HIP(p->smask.upload(sm));
+  }
   if (klist.empty()) klist.push_back(0);
-  p->nklist = (int)klist.size();
+  p->nklist = std::max((int)klist.size(), (Kc + 3) / 4 + 1);     // the LDS k-list area doubles as the super-step mask table (ksplit)
   TZ_HIP(p->klist.upload(klist)); TZ_HIP(p->items.upload(items_sorted)); TZ_HIP(p->item_ptr.upload(item_ptr));
   TZ_HIP(p->q.upload(d->q)); TZ_HIP(p->h.upload(d->h)); TZ_HIP(p->par.upload(d->par));
   TZ_HIP(p->par_lo.upload(d->par_lo, (size_t)p->npar)); TZ_HIP(p->par_hi.upload(d->par_hi, (size_t)p->npar));
@@ -427,7 +434,9 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   TZ_HIP(p->row_of.upload(d->row_of, (size_t)mi));
   TZ_HIP(p->act_scale.upload(d->act_scale, (size_t)mi));
 
-  p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist, p->ntheta) * sizeof(double);
+  p->ksplit = (p->Tz <= TZ_KS_TZ);
+  if (const char* e = getenv("TZ_KSPLIT")) { if (e[0] == '0') p->ksplit = false; }
+  p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist, p->ntheta, p->ksplit ? 1 : 0) * sizeof(double);
   if (mi > 4 * TZ_THREADS) TZ_FAIL(TZ_ERR_UNSUPPORTED, "mi=%d > %d inequality rows not supported by tz_ipm_kernel", mi, 4 * TZ_THREADS);
   if (p->lds_bytes > 160 * 1024)
     TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
