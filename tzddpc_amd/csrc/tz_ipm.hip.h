@@ -572,7 +572,11 @@ __host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp
 
 template <int MAXR, int NCG>
 __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmParams p) {
+#if TZ_PROFILE
   const bool PROF = p.prof != nullptr && blockIdx.x == 0;
+#else
+  constexpr bool PROF = false;            // the diagnostic build (libtzddpc_hip_prof.so, -DTZ_PROFILE=1) carries the per-phase clocks
+#endif
   unsigned long long tprev = 0, tstart = 0;
   unsigned long long acc_ph[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define TZ_STAMP(ph) do { if (PROF) { unsigned long long _t = __builtin_amdgcn_s_memtime(); acc_ph[ph] += _t - tprev; tprev = _t; } } while (0)

@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef TZ_PROFILE
+#define TZ_PROFILE 0
+#endif
 #define TZ_THREADS 256
 #define TZ_NWAVES 4
 #define TZ_NMAX 8          // max dim_x supported by the tube kernel's register arrays

@@ -444,6 +444,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg);
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
   if (const char* e = getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
+  if (p->prof && !TZ_PROFILE) TZ_FAIL(TZ_ERR_INVALID, "TZ_PROF=1 needs the diagnostic build of the library (libtzddpc_hip_prof.so)");
   if (const char* e = getenv("TZ_WARM")) { p->warm_enabled = (e[0] != '0'); }
   if (const char* e = getenv("TZ_FUSE")) { p->fuse_enabled = (e[0] != '0'); }
   if ((size_t)p->pmax * p->n > (size_t)p->nquads * TZ_QSTR) p->fuse_enabled = false;   // tube scratch borrows the factor storage
