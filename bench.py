@@ -151,11 +151,10 @@ def main():
 
     if rank == 0:
         # roofline of the dominant kernel (tz_ipm_kernel): useful MFMA flops of the static plan x iterations
-        plan = nat.plan_info()
         work = nat.work_get()                # counted on the device by tz_ipm_kernel during the timed launches
         fact_per_launch = work["factorizations"] / max(ipm_n, 1)
         iters_mean = work["factorizations"] / max(work["trajectory_solves"], 1)
-        flop_per_launch = (plan["mfma_gram_per_iter"] + plan["mfma_chol_per_iter"]) * 512.0 * fact_per_launch
+        flop_per_launch = nat.alg_flops["per_factorization"] * fact_per_launch
         avg_ms = ipm_ms / max(ipm_n, 1)
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
         line = {
@@ -173,7 +172,11 @@ def main():
                          "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "kernel": "tz_ipm_kernel", "avg_launch_ms": avg_ms, "launches": int(ipm_n),
                          "flop_per_launch": flop_per_launch,
-                         "note": "useful v_mfma_f64_4x4x4 flops of the static plan (Gram G'WG + Cholesky trailing updates) x factorisations counted on the device"},
+                         "flop_per_factorization": nat.alg_flops["per_factorization"],
+                         "dense_flop_per_factorization": nat.alg_flops["dense_per_factorization"],
+                         "note": "algorithmic f64 flops of one interior-point factorisation counted on the non-zeros of G (sparse outer products "
+                                 "for G'WG, Cholesky, four G/G' products, two solve pairs, P x) x factorisations counted on the device; the dense "
+                                 "count is given beside it; prologue / recovery / plant work of the fused step is not counted"},
         }
         line["config"]["gathered_rows"] = int(gathered.shape[0])
         if not args.no_cpu_baseline and world == 1:

@@ -48,7 +48,7 @@ def lib():
 
 
 class COracle:
-    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.9999, warm_floor=1e-5, warm_gain=1.0, mu_factor=0.1):
+    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999, warm_floor=1e-8, warm_gain=1.0, mu_factor=0.1):
         self.qp = qp
         self._keep = []
         d = Desc()

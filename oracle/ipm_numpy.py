@@ -26,7 +26,7 @@ class IpmOptions:
     max_iter: int = 40
     tol: float = 1e-9          # scaled residual / gap tolerance
     reg: float = 1e-13         # static primal regularisation (absolute; the scaled problem has O(1) entries)
-    step_frac: float = 0.9999
+    step_frac: float = 0.99999
     scaling_iters: int = 15
     refine: int = 2
 

@@ -104,7 +104,7 @@ struct tz_problem {
   int lastB = 0;
   bool prof = false;
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
-  double warm_floor = 1e-5, warm_gain = 1.0, warm_cold = 0.0, sf_gain = 0.0, sf_cap = 1.0, mu_factor = 0.1;
+  double warm_floor = 1e-8, warm_gain = 1.0, warm_cold = 0.0, sf_gain = 0.0, sf_cap = 1.0, mu_factor = 0.1;
   bool warm_enabled = true;
   bool ksplit = false;         // Gram by k-split (Tz <= TZ_KS_TZ; TZ_KSPLIT=0 keeps the item plan)
   bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_FUSE=0: four kernels per step, same arithmetic)
@@ -454,6 +454,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (const char* e = getenv("TZ_SF_GAIN")) p->sf_gain = atof(e);
   if (const char* e = getenv("TZ_SF_CAP")) p->sf_cap = atof(e);
   if (const char* e = getenv("TZ_MU_FACTOR")) p->mu_factor = atof(e);
+  if (const char* e = getenv("TZ_STEP_FRAC")) { double v = atof(e); if (v > 0 && v < 1) p->step_frac = v; }
   if (p->prof) TZ_HIP(p->prof_buf.alloc(PH_COUNT));
   TZ_HIP(p->work_buf.alloc(2));
   TZ_HIP(hipMemset(p->work_buf.p, 0, 2 * sizeof(unsigned long long)));

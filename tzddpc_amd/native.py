@@ -149,7 +149,7 @@ class Problem:
 
     def __init__(self, device: int, *, n, m, N, P, G, q0, Qt, h0, Ht, par0, Part, par_lo, par_hi, cost_scale, r0, r1, R2,
                  Dz, Phi, Gam, nc_rows, row_of, act_scale, CK, DK, K, pmax, absCKpow, absKCKpow, power,
-                 max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.9999):
+                 max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999):
         L = lib()
         keep = []
         d = ProblemDesc()
@@ -172,6 +172,14 @@ class Problem:
         d.pmax = int(pmax); d.power = _ptr(pw, _ip)
         d.max_iter = int(max_iter); d.tol = float(tol); d.reg = float(reg); d.step_frac = float(step_frac)
         self.n, self.m, self.N, self.nz, self.mi, self.nc_rows, self.ntheta = int(n), int(m), int(N), d.nz, d.mi, int(nc_rows), d.ntheta
+        # structure-aware algorithmic work of one interior-point factorisation + its two solves (what bench.py's roofline
+        # counts): sparse outer products of the rows of G, Cholesky, four G / G' products, two triangular solve pairs, P x
+        Gn = np.asarray(G).reshape(d.mi, d.nz); nnz_r = (Gn != 0).sum(axis=1).astype(np.float64)
+        self.alg_flops = dict(gram=float((nnz_r * (nnz_r + 1)).sum()), cholesky=float(d.nz) ** 3 / 3.0,
+                              g_products=8.0 * float(nnz_r.sum()), solves=8.0 * float(d.nz) ** 2,
+                              p_products=2.0 * float((np.asarray(P) != 0).sum()))
+        self.alg_flops["per_factorization"] = float(sum(self.alg_flops.values()))
+        self.alg_flops["dense_per_factorization"] = float(d.mi * d.nz * (d.nz + 1) + d.nz ** 3 / 3.0 + 8.0 * d.mi * d.nz + 10.0 * d.nz ** 2)
         h = C.c_void_p()
         check(L.tz_problem_create(int(device), C.byref(d), C.byref(h)), "tz_problem_create")
         self._h = h

@@ -193,7 +193,7 @@ class TZDDPC(object):
         self._scal = (D, E, c)
         self._row_of = row_of
         opts = dict(max_iter=int(solver_kwargs.pop("max_iter", 40)), tol=float(solver_kwargs.pop("tol", 1e-10)),
-                    reg=float(solver_kwargs.pop("reg", 1e-12)), step_frac=float(solver_kwargs.pop("step_frac", 0.9999)))
+                    reg=float(solver_kwargs.pop("reg", 1e-12)), step_frac=float(solver_kwargs.pop("step_frac", 0.99999)))
         self._drop_native()
         self._native = native.Problem(
             self.device, n=n, m=m, N=int(horizon),
