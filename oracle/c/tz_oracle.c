@@ -38,6 +38,7 @@ typedef struct tzo_desc {
   int32_t max_iter; double tol, reg, step_frac;
   double warm_floor, warm_gain;   /* closed-loop warm start (tzo_simulate_batch): see ipm() */
   double mu_tol;                  /* complementarity target (<= tol) */
+  double aff_thr, aff_mu;         /* predictor step taken as the step when it is (nearly) full and leaves mu_aff <= aff_mu mu */
 } tzo_desc;
 
 typedef struct {
@@ -226,6 +227,12 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
     double muaff = 0;
     for (int r = 0; r < mi; ++r) muaff += (s[r] + ap * ds[r]) * (lam[r] + ad * dl[r]);
     muaff /= mi;
+    if (fmin(ap, ad) >= d->aff_thr && muaff <= d->aff_mu * mu) {      /* no corrector: the Newton step itself */
+      double alphaA = fmin(1.0, d->step_frac * fmin(max_step(mi, s, ds), max_step(mi, lam, dl)));
+      for (int c = 0; c < nz; ++c) x[c] += alphaA * dx[c];
+      for (int r = 0; r < mi; ++r) { s[r] += alphaA * ds[r]; lam[r] += alphaA * dl[r]; gx[r] += alphaA * (-rp[r] - ds[r]); }
+      continue;
+    }
     double sigma = muaff / mu; sigma = sigma * sigma * sigma;
     /* corrector */
     for (int r = 0; r < mi; ++r) { rc[r] = s[r] * lam[r] + ds[r] * dl[r] - sigma * mu; t1[r] = (-rc[r] + lam[r] * rp[r]) / s[r]; }

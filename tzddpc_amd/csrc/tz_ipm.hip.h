@@ -41,6 +41,8 @@ struct IpmParams {
   int ksplit;                 // Gram by tz_form_H_ksplit (Tz <= TZ_KS_TZ) instead of the item plan
   int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
   double warm_gain, warm_cold;   // warm point pushed into the cone by max(warm_floor, warm_gain * violation); violation > warm_cold: cold start
+  double aff_thr, aff_mu;        // predictor step taken as the step (no corrector solve) when it reaches aff_thr of the way to the
+                                 // boundary un-damped and leaves mu_aff <= aff_mu * mu; aff_thr > 1 disables
   double sf_gain, sf_cap;        // fraction to the boundary = min(sf_cap, max(step_frac, 1 - sf_gain * mu))
   unsigned long long* work;   // [0] += factorisations, [1] += solved trajectories (bench.py roofline accounting); may be null
   unsigned long long* prof;   // TZ_PROF=1: per-phase cycle sums of workgroup 0 (diagnostic; no output depends on it)
@@ -777,6 +779,16 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     TZ_ROWS(k, r) muaff += (s_[k] + ap * ds_[k]) * (l_[k] + ad * dl_[k]);
     tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(muaff, z1, z2, red);
     muaff /= mi;
+    if (fmin(ap, ad) >= p.aff_thr && muaff <= p.aff_mu * mu) {
+      // the Newton (predictor) step is already (almost) a full step and kills complementarity: take it, skip the corrector
+      const double mmA = fmax(mp, md);
+      const double sfrA = (p.sf_gain > 0.0) ? fmin(p.sf_cap, fmax(p.step_frac, 1.0 - p.sf_gain * mu)) : p.step_frac;
+      const double alphaA = (mmA > sfrA) ? sfrA / mmA : 1.0;
+      for (int c = t; c < nz; c += TZ_THREADS) { xv[c] += alphaA * dxv[c]; rdv[c] *= (1.0 - alphaA); }
+      TZ_ROWS(k, r) { s_[k] += alphaA * ds_[k]; l_[k] += alphaA * dl_[k]; gx_[k] += alphaA * g_[k]; }
+      __syncthreads();
+      continue;
+    }
     double sigma = muaff / mu; sigma = sigma * sigma * sigma;
     // ---- corrector: rc = s*lam + dsa*dla - sigma mu -----------------------------------------------
     TZ_ROWS(k, r) {

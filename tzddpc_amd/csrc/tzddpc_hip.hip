@@ -104,7 +104,7 @@ struct tz_problem {
   int lastB = 0;
   bool prof = false;
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
-  double warm_floor = 1e-8, warm_gain = 1.0, warm_cold = 0.0, sf_gain = 0.0, sf_cap = 1.0, mu_factor = 0.1;
+  double warm_floor = 1e-8, warm_gain = 1.0, warm_cold = 0.0, sf_gain = 0.0, sf_cap = 1.0, mu_factor = 0.1, aff_thr = 0.99, aff_mu = 1e-3;
   bool warm_enabled = true;
   bool ksplit = false;         // Gram by k-split (Tz <= TZ_KS_TZ; TZ_KSPLIT=0 keeps the item plan)
   bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_FUSE=0: four kernels per step, same arithmetic)
@@ -189,7 +189,7 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.work = p->timing ? p->work_buf.p : nullptr;
   ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0;
   ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
-  ip.warm_gain = p->warm_gain; ip.warm_cold = p->warm_cold; ip.sf_gain = p->sf_gain; ip.sf_cap = p->sf_cap;
+  ip.warm_gain = p->warm_gain; ip.warm_cold = p->warm_cold; ip.sf_gain = p->sf_gain; ip.sf_cap = p->sf_cap; ip.aff_thr = p->aff_thr; ip.aff_mu = p->aff_mu;
   ip.prev_status = warm ? p->prev_status.p : nullptr;
   ip.status_copy = track_prev ? p->prev_status.p : nullptr;
   ip.F.on = 0;
@@ -454,6 +454,8 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (const char* e = getenv("TZ_SF_GAIN")) p->sf_gain = atof(e);
   if (const char* e = getenv("TZ_SF_CAP")) p->sf_cap = atof(e);
   if (const char* e = getenv("TZ_MU_FACTOR")) p->mu_factor = atof(e);
+  if (const char* e = getenv("TZ_AFF_THR")) p->aff_thr = atof(e);
+  if (const char* e = getenv("TZ_AFF_MU")) p->aff_mu = atof(e);
   if (const char* e = getenv("TZ_STEP_FRAC")) { double v = atof(e); if (v > 0 && v < 1) p->step_frac = v; }
   if (p->prof) TZ_HIP(p->prof_buf.alloc(PH_COUNT));
   TZ_HIP(p->work_buf.alloc(2));

@@ -17,6 +17,8 @@ TZ_SOLVED, TZ_MAX_ITER, TZ_NUMERICAL, TZ_INFEASIBLE = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtzddpc_hip_prof.so" if os.environ.get("TZ_PROF") == "1" else "libtzddpc_hip.so")
+if os.environ.get("TZ_LIB"):                      # diagnostic builds (tools/): explicit library file
+    LIB_PATH = os.path.abspath(os.environ["TZ_LIB"])
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
