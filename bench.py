@@ -166,8 +166,8 @@ def main():
                                    f"(BASELINE.json configs[1]), complexity-script zonotopes, vertex-of-W noise PCG64(1000+i)",
                        "trajectories_per_gpu": Bl, "horizon": args.horizon, "nz": ctl.qp.nz, "rows": int(nat.mi),
                        "ipm_factorizations_per_trajectory_step": iters_mean, "warm_start": os.environ.get("TZ_WARM", "1") != "0", "unsolved_trajectory_steps": int(nbad.item()),
-                       "kernel_ms_per_step": {"tz_tube+affine": prep_ms / max(ipm_n, 1), "tz_ipm": avg_ms, "tz_finish": fin_ms / max(ipm_n, 1),
-                                              "tz_plant": plant_ms / max(ipm_n, 1)}},
+                       "kernel_ms_per_step": {"tz_tube+affine": prep_ms / K, "tz_ipm": ipm_ms / K, "tz_finish": fin_ms / K, "tz_plant": plant_ms / K},
+                       "steps_per_launch": K / max(ipm_n, 1)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "kernel": "tz_ipm_kernel", "avg_launch_ms": avg_ms, "launches": int(ipm_n),

@@ -569,7 +569,7 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
 __host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit) {
-  return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 10 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta;
+  return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 10 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX;
 }
 
 template <int MAXR, int NCG>
@@ -609,27 +609,14 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   int* flag = (int*)(red + 16);
   int* kl = (int*)(red + 18);
   double* thl = red + 18 + (p.nklist + 1) / 2;      // theta of this trajectory (fused step only)
-  double* Pq = thl + p.F.ntheta;                    // ksplit: P + reg I in the quad layout of Hq (lower tiles)
+  double* stl = thl + p.F.ntheta;                   // fused: closed-loop state [x | xbar | e] (3 TZ_NMAX doubles)
+  double* Pq = stl + 3 * TZ_NMAX;                   // ksplit: P + reg I in the quad layout of Hq (lower tiles)
 
   // rows owned by this thread
   double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR], w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR], is_[MAXR], il_[MAXR];
 #define TZ_ROWS(k, r) _Pragma("unroll") for (int k = 0; k < MAXR; ++k) if (const int r = t + TZ_THREADS * k; r < mi)
 
-  bool skip = false;                        // fused step: a parameter row is violated -> status 3, u = K e, nominal state from Phi
-  if (fused) {
-    if (t == 0) { flag[0] = 0; flag[1] = 0; }
-    tz_tube_block(F.tube, b, Hq, thl, t, TZ_THREADS);       // the factor storage is free until the first Gram
-    __syncthreads();
-    for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? csr_row(F.qmap, c, thl) : 0.0; xv[c] = 0.0; }
-    int bad = 0;
-    for (int r = t; r < F.npar; r += TZ_THREADS) {
-      const double v = csr_row(F.parmap, r, thl);
-      if (!(v >= F.par_lo[r] - 1e-9) || !(v <= F.par_hi[r] + 1e-9)) bad = 1;
-    }
-    if (bad) flag[1] = 1;
-  } else
-  for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? p.q[(size_t)b * nz + c] : 0.0; xv[c] = 0.0; }
-  for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the start point
+  // ---- once per launch: constants of the problem into LDS, closed-loop state of the trajectory -------------------------
   if (p.ksplit) {
     for (int i = t; i <= ((p.Kc + 3) >> 2); i += TZ_THREADS) kl[i] = p.smask[i];
     for (int e = t; e < p.nquads * 64; e += TZ_THREADS) {                // every entry of every quad (padding tiles: 0)
@@ -643,12 +630,47 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     }
   }
   else for (int i = t; i < p.nklist; i += TZ_THREADS) kl[i] = p.klist[i];
+  if (fused && t < F.fin.n) {                     // closed-loop state [x | xbar | e] stays in LDS for all steps of this launch
+    stl[t] = F.plant.x[(size_t)b * F.fin.n + t];
+    stl[F.fin.n + t] = F.plant.xbar[(size_t)b * F.fin.n + t];
+    stl[2 * F.fin.n + t] = F.plant.e[(size_t)b * F.fin.n + t];
+  }
 #pragma unroll
   for (int k = 0; k < MAXR; ++k) { s_[k] = 1.0; l_[k] = 0.0; h_[k] = 0.0; gx_[k] = 0.0; w_[k] = 0.0; rp_[k] = 0.0; ds_[k] = 0.0; dl_[k] = 0.0; g_[k] = 0.0; is_[k] = 1.0; il_[k] = 1.0; }
-  if (fused) { TZ_ROWS(k, r) { h_[k] = csr_row(F.hmap, r, thl); l_[k] = 1.0; } }
-  else { TZ_ROWS(k, r) { h_[k] = p.h[(size_t)b * mi + r]; l_[k] = 1.0; } if (t == 0) *flag = 0; }
+  for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
   __syncthreads();
-  if (fused && flag[1] != 0) { skip = true; TZ_ROWS(k, r) l_[k] = 0.0; }
+
+  const int nsteps = fused ? F.nsteps : 1;
+  int status = 1, it = 0;
+  unsigned long long work_f = 0, work_s = 0;
+  for (int step = 0; step < nsteps; ++step) {     // closed-loop steps of this trajectory (one when the launch is a single solve)
+  // start point of this step: 0 cold, 1 the (x, lambda) stored by an earlier launch, 2 the (x, lambda) of the previous step (still
+  // in LDS / registers)
+  int src = 0;
+  if (step == 0) src = (p.warm != 0 && p.prev_status != nullptr && p.prev_status[b] == 0) ? 1 : 0;
+  else src = (F.warm_steps != 0 && status == 0) ? 2 : 0;
+  bool skip = false;                        // fused step: a parameter row is violated -> status 3, u = K e, nominal state from Phi
+  for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the cold start point
+  if (fused) {
+    if (t == 0) { flag[0] = 0; flag[1] = 0; }
+    tz_tube_block(F.tube, stl + F.fin.n, stl + 2 * F.fin.n, Hq, thl, t, TZ_THREADS);       // the factor storage is free until the first Gram
+    __syncthreads();
+    for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? csr_row(F.qmap, c, thl) : 0.0; if (src != 2) xv[c] = 0.0; }
+    int bad = 0;
+    for (int r = t; r < F.npar; r += TZ_THREADS) {
+      const double v = csr_row(F.parmap, r, thl);
+      if (!(v >= F.par_lo[r] - 1e-9) || !(v <= F.par_hi[r] + 1e-9)) bad = 1;
+    }
+    if (bad) flag[1] = 1;
+    TZ_ROWS(k, r) h_[k] = csr_row(F.hmap, r, thl);
+  } else {
+    for (int c = t; c < nzp; c += TZ_THREADS) qv[c] = (c < nz) ? p.q[(size_t)b * nz + c] : 0.0;
+    TZ_ROWS(k, r) h_[k] = p.h[(size_t)b * mi + r];
+    if (t == 0) *flag = 0;
+  }
+  if (src != 2) { TZ_ROWS(k, r) l_[k] = 1.0; }
+  __syncthreads();
+  if (fused && flag[1] != 0) { skip = true; TZ_ROWS(k, r) { s_[k] = 1.0; l_[k] = 0.0; } for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0; }
   TZ_STAMP(PH_PROLOGUE);
 
   // exact dual residual rd = P x + q + G'lam into rdv (used at the start and to confirm convergence)
@@ -666,13 +688,13 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   };
 
   bool okf = true;
-  bool warm = !skip && p.warm != 0 && p.prev_status != nullptr && p.prev_status[b] == 0;     // previous step of this trajectory was solved: start from it
+  bool warm = !skip && src != 0;     // the previous step of this trajectory was solved: start from it
   double scq = 0, sch = 0;
   if (!skip) {
   if (warm) {
     // ---- warm start: previous (x, lambda) of this trajectory, slacks re-derived for the new h and pushed into the cone
     // by at least the amount the old point violates the new rows; a point that is too far outside starts cold instead
-    for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + c];
+    if (src == 1) { for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + c]; TZ_ROWS(k, r) l_[k] = p.lam[(size_t)b * mi + r]; }
     __syncthreads();
     tz_gemv_G<MAXR>(p, xv, gx_);
     double viol = 0.0, zv1 = 0.0, zv2 = 0.0;
@@ -680,13 +702,14 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, zv1, zv2, red);
     if (p.warm_cold > 0.0 && viol > p.warm_cold) {
       warm = false;
+      TZ_ROWS(k, r) l_[k] = 1.0;
       for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
       __syncthreads();
     } else {
       const double sig = fmax(p.warm_floor, p.warm_gain * viol);
       TZ_ROWS(k, r) {
         s_[k] = fmax(h_[k] - gx_[k], sig);
-        l_[k] = fmax(p.lam[(size_t)b * mi + r], sig);
+        l_[k] = fmax(l_[k], sig);
       }
     }
   }
@@ -719,7 +742,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   }
   const double sc_d = 1.0 + scq, sc_p = 1.0 + sch;
 
-  int status = skip ? 3 : (okf ? 1 : 2), it = 0;
+  status = skip ? 3 : (okf ? 1 : 2);
   for (it = 0; it < p.max_iter && status == 1; ++it) {
     TZ_STAMP(PH_ELEM);
     // residuals: rd is carried along (Newton on a linear residual: rd <- (1 - alpha) rd) and re-evaluated exactly before
@@ -825,18 +848,21 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     TZ_ROWS(k, r) { s_[k] += alpha * ds_[k]; l_[k] += alpha * dl_[k]; gx_[k] += alpha * g_[k]; }
     __syncthreads();
   }
-  for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = xv[c];
-  TZ_ROWS(k, r) { p.s[(size_t)b * mi + r] = s_[k]; p.lam[(size_t)b * mi + r] = l_[k]; }
-  if (t == 0) {
-    p.status[b] = status; p.iters[b] = it;
-    if (p.status_copy) p.status_copy[b] = status;
-    if (p.work) { atomicAdd(p.work, (unsigned long long)(it + (warm ? 0 : 1))); atomicAdd(p.work + 1, 1ull); }
+  work_f += (unsigned long long)(it + ((warm || skip) ? 0 : 1)); work_s += 1;
+  if (step == nsteps - 1) {                 // what a later launch (or the host) reads: solution, multipliers, status
+    for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = xv[c];
+    TZ_ROWS(k, r) { p.s[(size_t)b * mi + r] = s_[k]; p.lam[(size_t)b * mi + r] = l_[k]; }
+    if (t == 0) {
+      p.status[b] = status; p.iters[b] = it;
+      if (p.status_copy) p.status_copy[b] = status;
+      if (p.work) { atomicAdd(p.work, work_f); atomicAdd(p.work + 1, work_s); }
+    }
   }
   TZ_STAMP(PH_ELEM);
   if (fused) {
     // ---- recovery (tz_finish_kernel) and plant / error update (tz_plant_kernel) of this trajectory ----------------
     const int n = F.fin.n, m = F.fin.m, N = F.fin.N, nv = N * m;
-    const double* x0 = F.fin.xbar0 + (size_t)b * n;
+    const double* x0 = stl + n;                         // nominal state this step started from
     __syncthreads();
     tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
     for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = F.fin.Dz[c] * xv[c];
@@ -850,7 +876,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
         r += F.fin.r1[i] * x0[i];
         for (int j = 0; j < n; ++j) r += x0[i] * F.fin.R2[i * n + j] * x0[j];
       }
-      F.fin.cost[(size_t)b * F.fin.cost_stride] = (status == 0 || status == 1) ? acc / F.fin.cost_scale + r : INFINITY;
+      F.fin.cost[(size_t)b * F.fin.cost_stride + (size_t)step * F.cost_step] = (status == 0 || status == 1) ? acc / F.fin.cost_scale + r : INFINITY;
       if (F.plant.sticky && F.plant.sticky[b] == 0 && status != 0) F.plant.sticky[b] = status;
     }
     if (F.fin.v) for (int c = t; c < nv; c += TZ_THREADS) F.fin.v[(size_t)b * nv + c] = dxv[c];
@@ -867,13 +893,13 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       const PlantParams& Q = F.plant;
       double xn = 0.0, xb = 0.0;
       if (t < n) {
-        xn = Q.w[(size_t)b * Q.w_stride + t];
-        for (int j = 0; j < n; ++j) xn += Q.A[t * n + j] * Q.x[(size_t)b * n + j];
+        xn = Q.w[(size_t)b * Q.w_stride + (size_t)step * F.w_step + t];
+        for (int j = 0; j < n; ++j) xn += Q.A[t * n + j] * stl[j];
         for (int j = 0; j < m; ++j) {
           double u = dxv[j];
-          for (int i = 0; i < n; ++i) u += Q.K[j * n + i] * Q.e[(size_t)b * n + i];
+          for (int i = 0; i < n; ++i) u += Q.K[j * n + i] * stl[2 * n + i];
           xn += Q.Bm[t * m + j] * u;
-          if (t == 0 && Q.u_out) Q.u_out[(size_t)b * Q.u_stride + j] = u;
+          if (t == 0 && Q.u_out) Q.u_out[(size_t)b * Q.u_stride + (size_t)step * F.u_step + j] = u;
         }
         xb = tmpz[t];
       }
@@ -881,11 +907,14 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       __builtin_amdgcn_wave_barrier();                       // every lane has read the old state before any lane overwrites it
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (t < n) {
-        Q.x[(size_t)b * n + t] = xn; Q.xbar[(size_t)b * n + t] = xb; Q.e[(size_t)b * n + t] = xn - xb;
-        if (Q.x_out) Q.x_out[(size_t)b * Q.x_stride + t] = xn;
+        stl[t] = xn; stl[n + t] = xb; stl[2 * n + t] = xn - xb;
+        if (step == nsteps - 1) { Q.x[(size_t)b * n + t] = xn; Q.xbar[(size_t)b * n + t] = xb; Q.e[(size_t)b * n + t] = xn - xb; }
+        if (Q.x_out) Q.x_out[(size_t)b * Q.x_stride + (size_t)step * F.x_step + t] = xn;
       }
     }
+    __syncthreads();                          // the next step's tube pass reads the state
   }
+  }   // steps
   if (PROF && t == 0) {
     TZ_STAMP(PH_EPILOGUE);
     acc_ph[PH_TOTAL] = tprev - tstart; acc_ph[7] = (unsigned long long)it;

@@ -54,16 +54,15 @@ struct TubeParams {
 #define TZ_PMAX 128        // highest supported power of M_K
 // All nt threads of the workgroup (tid) work on trajectory b.  aL: pmax * n doubles of LDS scratch; th: ntheta doubles (LDS or
 // global).  Contains one workgroup barrier; the caller adds another before th is read by other threads.
-__device__ inline void tz_tube_block(const TubeParams& p, int b, double* aL, double* th, int tid, int nt) {
+__device__ inline void tz_tube_block(const TubeParams& p, const double* xbar0, const double* e0, double* aL, double* th, int tid, int nt) {
   const int n = p.n, m = p.m, hs = 2 * n + m;
-  const double* e0 = p.e0 + (size_t)b * n;
   for (int e = tid; e < p.pmax * n; e += nt) {
     const double* M = p.CKpow + (size_t)e * n;            // row i of C_K^l with e = l n + i
     double a = 0.0;
     for (int j = 0; j < n; ++j) a += M[j] * e0[j];
     aL[e] = fabs(a);
   }
-  if (tid < n) { const double x0 = p.xbar0[(size_t)b * n + tid]; th[tid] = x0; th[n + tid] = fabs(x0); }
+  if (tid < n) { const double x0 = xbar0[tid]; th[tid] = x0; th[n + tid] = fabs(x0); }
   __syncthreads();
   for (int e = tid; e < p.N * hs; e += nt) {
     const int k = e / hs, idx = e % hs, pw = p.power[k];
@@ -86,7 +85,7 @@ __device__ inline void tz_tube_block(const TubeParams& p, int b, double* aL, dou
 __global__ __launch_bounds__(64) void tz_tube_kernel(TubeParams p) {
   __shared__ double aL[TZ_PMAX * TZ_NMAX];
   const int b = blockIdx.x;
-  tz_tube_block(p, b, aL, p.theta + (size_t)b * p.ntheta, threadIdx.x, 64);
+  tz_tube_block(p, p.xbar0 + (size_t)b * p.n, p.e0 + (size_t)b * p.n, aL, p.theta + (size_t)b * p.ntheta, threadIdx.x, 64);
   if (threadIdx.x == 0) p.prestatus[b] = 0;
 }
 
@@ -156,6 +155,8 @@ struct PlantParams {
 struct FuseParams {
   int on;
   int npar, ntheta;
+  int nsteps, warm_steps;           // closed-loop steps done by this launch; warm_steps: step k+1 starts from the solution of step k
+  size_t w_step, u_step, x_step, cost_step;   // element offsets per step into plant.w / plant.u_out / plant.x_out / fin.cost
   TubeParams tube;
   TzCsr qmap, hmap, parmap;
   const double* par_lo; const double* par_hi;

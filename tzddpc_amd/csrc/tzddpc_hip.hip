@@ -198,14 +198,18 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
 
 // One closed-loop step of B trajectories in ONE launch (tz_ipm_kernel with F.on): tube, parameter maps, interior point,
 // recovery / objective and plant update; theta, q and h never reach HBM.  Same arithmetic as launch_solve + launch_plant.
+struct StepStrides { size_t w, u, x, cost; };     // element offsets per closed-loop step inside one launch
 int launch_step_fused(tz_problem* p, int B, double* d_x, double* d_xbar, double* d_e, const double* d_w, size_t w_stride,
                       const double* d_A, const double* d_Bm, double* d_u, size_t u_stride, double* d_xout, size_t x_stride,
-                      double* d_cost, size_t cost_stride, int* d_status, int* d_sticky, bool warm) {
+                      double* d_cost, size_t cost_stride, int* d_status, int* d_sticky, bool warm,
+                      int nsteps = 1, StepStrides ss = StepStrides{0, 0, 0, 0}) {
   p->lastB = B;
   Timer tm(p, K_IPM);
   IpmParams ip = ipm_params(p, B, d_status, p->iters.p, warm, true);
   FuseParams& F = ip.F;
   F.on = 1; F.npar = p->npar; F.ntheta = p->ntheta;
+  F.nsteps = nsteps; F.warm_steps = p->warm_enabled ? 1 : 0;
+  F.w_step = ss.w; F.u_step = ss.u; F.x_step = ss.x; F.cost_step = ss.cost;
   F.tube = TubeParams{B, p->n, p->m, p->N, p->pmax, p->ntheta, p->CKpow.p, p->Ttube.p, p->power.p, d_xbar, d_e, nullptr, nullptr};
   F.qmap = p->q.view(); F.hmap = p->h.view(); F.parmap = p->par.view(); F.par_lo = p->par_lo.p; F.par_hi = p->par_hi.p;
   F.fin = FinishParams{B, p->n, p->m, p->N, p->nz, p->mi, p->nzp, p->nc_rows, p->P.p, p->Dz.p, p->Phi.p, p->Gam.p,
@@ -551,15 +555,16 @@ int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, dou
   int rc = ensure_workspace(p, B);
   if (rc) return rc;
   TZ_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int), p->stream));
+  if (p->fuse_enabled) {                    // all K steps of every trajectory in ONE launch: the state never leaves the workgroup
+    const bool warm = p->warm_enabled && p->have_prev && p->prevB == B;
+    rc = launch_step_fused(p, B, x, xbar, e, w, (size_t)p->n, A_true, B_true, u_out, (size_t)p->m, nullptr, 0,
+                           cost, 1, p->status.p, status, warm, K, StepStrides{(size_t)B * p->n, 0, 0, 0});
+    if (rc) return rc;
+    p->have_prev = true; p->prevB = B;
+    return TZ_OK;
+  }
   for (int t = 0; t < K; ++t) {
     const bool warm = p->warm_enabled && p->have_prev && p->prevB == B;
-    if (p->fuse_enabled) {
-      rc = launch_step_fused(p, B, x, xbar, e, w + (size_t)t * B * p->n, (size_t)p->n, A_true, B_true, u_out, (size_t)p->m, nullptr, 0,
-                             cost, 1, p->status.p, status, warm);
-      if (rc) return rc;
-      p->have_prev = true; p->prevB = B;
-      continue;
-    }
     rc = launch_solve(p, B, xbar, e, p->v.p, p->xbar.p, cost, p->status.p, p->iters.p, nullptr, 1, warm, true);
     if (rc) return rc;
     p->have_prev = true; p->prevB = B;
@@ -601,14 +606,13 @@ int tz_simulate_batch(tz_problem* p, int32_t B, int32_t T, const double* x0, con
   TZ_HIP(hipMemcpyAsync(p->st_xbar.p, p->st_x.p, (size_t)B * n * sizeof(double), hipMemcpyDeviceToDevice, st));   // xbar = x0 (:69)
   TZ_HIP(hipMemsetAsync(p->st_e.p, 0, (size_t)B * n * sizeof(double), st));                                        // e = 0   (:70)
   TZ_HIP(hipMemsetAsync(p->sticky.p, 0, (size_t)B * sizeof(int), st));
-  for (int t = 0; t < T; ++t) {
-    if (p->fuse_enabled) {
-      rc = launch_step_fused(p, B, p->st_x.p, p->st_xbar.p, p->st_e.p, dnoise + (size_t)t * n, (size_t)T * n, dA, dB,
-                             du + (size_t)t * m, (size_t)T * m, dx + (size_t)(t + 1) * n, (size_t)(T + 1) * n,
-                             dcost + t, (size_t)T, p->status.p, p->sticky.p, p->warm_enabled && t > 0);
-      if (rc) return rc;
-      continue;
-    }
+  if (p->fuse_enabled) {
+    rc = launch_step_fused(p, B, p->st_x.p, p->st_xbar.p, p->st_e.p, dnoise, (size_t)T * n, dA, dB,
+                           du, (size_t)T * m, dx + n, (size_t)(T + 1) * n,
+                           dcost, (size_t)T, p->status.p, p->sticky.p, false, T, StepStrides{(size_t)n, (size_t)m, (size_t)n, 1});
+    if (rc) return rc;
+  }
+  for (int t = 0; t < T && !p->fuse_enabled; ++t) {
     rc = launch_solve(p, B, p->st_xbar.p, p->st_e.p, p->v.p, p->xbar.p, dcost + t, p->status.p, p->iters.p, nullptr, (size_t)T, p->warm_enabled && t > 0, true);
     if (rc) return rc;
     rc = launch_plant(p, B, dA, dB, dnoise + (size_t)t * n, (size_t)T * n, p->v.p, p->xbar.p, p->status.p,
