@@ -38,6 +38,7 @@ struct IpmParams {
   int* status_copy;         // optional second destination of the status (library-owned copy for the next step)
   int max_iter; double tol, reg, step_frac;
   double mu_tol;              // complementarity target (<= tol): the distance to the solution of a degenerate problem goes like sqrt(mu)
+  int warm_steps;             // multi-step launches: step k+1 starts from the solution of step k
   int ksplit;                 // Gram by tz_form_H_ksplit (Tz <= TZ_KS_TZ) instead of the item plan
   int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
   double warm_gain, warm_cold;   // warm point pushed into the cone by max(warm_floor, warm_gain * violation); violation > warm_cold: cold start
@@ -572,6 +573,8 @@ __host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp
   return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 10 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX;
 }
 
+typedef __attribute__((address_space(4))) const IpmParams* TzKargPtr;
+
 template <int MAXR, int NCG>
 __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmParams p) {
 #if TZ_PROFILE
@@ -587,8 +590,8 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   const int b = blockIdx.x;
   const int t = threadIdx.x;
   const int nz = p.nz, mi = p.mi, nzp = p.nzp, mip = p.mip;
-  const FuseParams& F = p.F;
-  const bool fused = F.on != 0;          // closed-loop step in one launch: tube + parameter maps before, recovery + plant after
+  const FuseParams& F0 = p.F;
+  const bool fused = F0.on != 0;          // closed-loop step in one launch: tube + parameter maps before, recovery + plant after
   if (!fused && p.prestatus[b] != 0) {
     if (t == 0) { p.status[b] = 3; p.iters[b] = 0; if (p.status_copy) p.status_copy[b] = 3; }
     for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = 0.0;
@@ -630,17 +633,17 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     }
   }
   else for (int i = t; i < p.nklist; i += TZ_THREADS) kl[i] = p.klist[i];
-  if (fused && t < F.fin.n) {                     // closed-loop state [x | xbar | e] stays in LDS for all steps of this launch
-    stl[t] = F.plant.x[(size_t)b * F.fin.n + t];
-    stl[F.fin.n + t] = F.plant.xbar[(size_t)b * F.fin.n + t];
-    stl[2 * F.fin.n + t] = F.plant.e[(size_t)b * F.fin.n + t];
+  if (fused && t < F0.fin.n) {                    // closed-loop state [x | xbar | e] stays in LDS for all steps of this launch
+    stl[t] = F0.plant.x[(size_t)b * F0.fin.n + t];
+    stl[F0.fin.n + t] = F0.plant.xbar[(size_t)b * F0.fin.n + t];
+    stl[2 * F0.fin.n + t] = F0.plant.e[(size_t)b * F0.fin.n + t];
   }
 #pragma unroll
   for (int k = 0; k < MAXR; ++k) { s_[k] = 1.0; l_[k] = 0.0; h_[k] = 0.0; gx_[k] = 0.0; w_[k] = 0.0; rp_[k] = 0.0; ds_[k] = 0.0; dl_[k] = 0.0; g_[k] = 0.0; is_[k] = 1.0; il_[k] = 1.0; }
   for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
   __syncthreads();
 
-  const int nsteps = fused ? F.nsteps : 1;
+  const int nsteps = fused ? F0.nsteps : 1;
   int status = 1, it = 0;
   unsigned long long work_f = 0, work_s = 0;
   for (int step = 0; step < nsteps; ++step) {     // closed-loop steps of this trajectory (one when the launch is a single solve)
@@ -648,7 +651,13 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   // in LDS / registers)
   int src = 0;
   if (step == 0) src = (p.warm != 0 && p.prev_status != nullptr && p.prev_status[b] == 0) ? 1 : 0;
-  else src = (F.warm_steps != 0 && status == 0) ? 2 : 0;
+  else src = (p.warm_steps != 0 && status == 0) ? 2 : 0;
+  // The fused-step arguments are needed only before and after the interior point: re-read them from the kernel argument
+  // segment here and in the epilogue (opaque pointer: the loads cannot be hoisted out of the step loop, so the ~120 scalar
+  // registers they would pin are free during the solve).
+  TzKargPtr kp0 = (TzKargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp0));
+  const FuseParams& F = ((const IpmParams*)kp0)->F;
   bool skip = false;                        // fused step: a parameter row is violated -> status 3, u = K e, nominal state from Phi
   for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the cold start point
   if (fused) {
@@ -860,6 +869,9 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   }
   TZ_STAMP(PH_ELEM);
   if (fused) {
+    TzKargPtr kp1 = (TzKargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp1));
+    const FuseParams& F = ((const IpmParams*)kp1)->F;
     // ---- recovery (tz_finish_kernel) and plant / error update (tz_plant_kernel) of this trajectory ----------------
     const int n = F.fin.n, m = F.fin.m, N = F.fin.N, nv = N * m;
     const double* x0 = stl + n;                         // nominal state this step started from

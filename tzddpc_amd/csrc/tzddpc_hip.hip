@@ -208,7 +208,7 @@ int launch_step_fused(tz_problem* p, int B, double* d_x, double* d_xbar, double*
   IpmParams ip = ipm_params(p, B, d_status, p->iters.p, warm, true);
   FuseParams& F = ip.F;
   F.on = 1; F.npar = p->npar; F.ntheta = p->ntheta;
-  F.nsteps = nsteps; F.warm_steps = p->warm_enabled ? 1 : 0;
+  F.nsteps = nsteps; F.warm_steps = p->warm_enabled ? 1 : 0; ip.warm_steps = F.warm_steps;
   F.w_step = ss.w; F.u_step = ss.u; F.x_step = ss.x; F.cost_step = ss.cost;
   F.tube = TubeParams{B, p->n, p->m, p->N, p->pmax, p->ntheta, p->CKpow.p, p->Ttube.p, p->power.p, d_xbar, d_e, nullptr, nullptr};
   F.qmap = p->q.view(); F.hmap = p->h.view(); F.parmap = p->par.view(); F.par_lo = p->par_lo.p; F.par_hi = p->par_hi.p;
