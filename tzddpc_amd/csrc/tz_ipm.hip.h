@@ -39,6 +39,7 @@ struct IpmParams {
   int max_iter; double tol, reg, step_frac;
   double mu_tol;              // complementarity target (<= tol): the distance to the solution of a degenerate problem goes like sqrt(mu)
   int warm_steps;             // multi-step launches: step k+1 starts from the solution of step k
+  int chol1;                  // Tz <= 16: one wave factors H while the other three form the predictor's right-hand side
   int ksplit;                 // Gram by tz_form_H_ksplit (Tz <= TZ_KS_TZ) instead of the item plan
   int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
   double warm_gain, warm_cold;   // warm point pushed into the cone by max(warm_floor, warm_gain * violation); violation > warm_cold: cold start
@@ -119,20 +120,21 @@ __device__ inline void tz_gemv_G(const IpmParams& p, const double* in, double (&
 
 // part[w][c] = sum over the rows r = w, w+4, ... of M[r][c] in[r]  (row-major M, rows x nzp; `in` in LDS).
 // NCG = ceil(nzp / 64) column groups per lane.  The four per-wave partials are combined by tz_gemvT_get.
-template <int NCG>
+// W0 / NW: the product is shared by the NW waves W0 .. W0 + NW - 1 (the others must not call); partial sums part[0 .. NW).
+template <int NCG, int W0 = 0, int NW = TZ_NWAVES>
 __device__ inline void tz_gemvT_partial(const double* M, int rows, int nzp, const double* in, double* part) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) - W0;
   constexpr int UR = (NCG <= 2) ? 8 : 4;
   double acc[NCG];
 #pragma unroll
   for (int g = 0; g < NCG; ++g) acc[g] = 0.0;
   int r = w;
-  for (; r + (UR - 1) * TZ_NWAVES < rows; r += UR * TZ_NWAVES) {
+  for (; r + (UR - 1) * NW < rows; r += UR * NW) {
     double v[UR], m[UR][NCG];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      v[u] = in[r + u * TZ_NWAVES];
-      const double* row = M + (size_t)(r + u * TZ_NWAVES) * nzp;
+      v[u] = in[r + u * NW];
+      const double* row = M + (size_t)(r + u * NW) * nzp;
 #pragma unroll
       for (int g = 0; g < NCG; ++g) { const int c = min(lane + 64 * g, nzp - 1); m[u][g] = row[c]; }   // clamped: columns >= nzp are never stored
     }
@@ -141,7 +143,7 @@ __device__ inline void tz_gemvT_partial(const double* M, int rows, int nzp, cons
 #pragma unroll
       for (int g = 0; g < NCG; ++g) acc[g] += m[u][g] * v[u];
   }
-  for (; r < rows; r += TZ_NWAVES) {
+  for (; r < rows; r += NW) {
     const double v = in[r];
     const double* row = M + (size_t)r * nzp;
 #pragma unroll
@@ -152,6 +154,9 @@ __device__ inline void tz_gemvT_partial(const double* M, int rows, int nzp, cons
 }
 __device__ inline double tz_gemvT_get(const double* part, int nzp, int c) {
   return (part[c] + part[nzp + c]) + (part[2 * nzp + c] + part[3 * nzp + c]);
+}
+__device__ inline double tz_gemvT_get3(const double* part, int nzp, int c) {
+  return (part[c] + part[nzp + c]) + part[2 * nzp + c];
 }
 
 // Gram matrix  H = P + G' diag(w) G + reg I  into LDS quads, by v_mfma_f64_4x4x4 (blk = 4 column tiles).
@@ -486,6 +491,56 @@ __device__ inline bool tz_cholesky(const IpmParams& p, double* Hq, double* dinv,
   return *flag == 0;
 }
 
+// The same factorisation by ONE wave (wave-level ordering of its own LDS traffic instead of workgroup barriers), for matrices
+// of at most 16 tile columns: the other three waves are free to run an independent G' product meanwhile (tz_ipm_kernel).
+__device__ inline void tz_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ inline void tz_cholesky_wave(const IpmParams& p, double* Hq, double* dinv, int* flag) {
+  const int Tz = p.Tz;
+  const int lane = threadIdx.x & 63;
+  const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
+  for (int pp = 0; pp < Tz; ++pp) {
+    if (pp > 0) {
+      const int pq = pp >> 2, po = 4 * (pp & 3);
+      const double* pb = Hq + tz_qprefix(pp) * TZ_QSTR + TZ_QROW * ij + k;
+      for (int g = 0; pp + 4 * g < Tz; g += 2) {
+        const int Ia = pp + 4 * g + blk, Ib = Ia + 4;
+        const bool va = Ia < Tz, vb = Ib < Tz;
+        const int qa = tz_qprefix(va ? Ia : pp), qb = tz_qprefix(vb ? Ib : pp);
+        const double* pa = Hq + qa * TZ_QSTR + TZ_QROW * ij + k;
+        const double* pa2 = Hq + qb * TZ_QSTR + TZ_QROW * ij + k;
+        double* pc = Hq + (qa + pq) * TZ_QSTR + TZ_QROW * k + po + ij;
+        double* pc2 = Hq + (qb + pq) * TZ_QSTR + TZ_QROW * k + po + ij;
+        double a0 = *pc, a1 = 0.0, c0 = vb ? *pc2 : 0.0, c1 = 0.0;
+        int off = 0, k2 = 0;
+        for (; k2 + 1 < pp; k2 += 2) {
+          const int off1 = off + 4 + (((k2 & 3) == 3) ? TZ_QSTR - 16 : 0);
+          const double nb0 = -pb[off], nb1 = -pb[off1];
+          const double x0 = pa[off], x1 = pa[off1], y0 = pa2[off], y1 = pa2[off1];
+          a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(x0, nb0, a0, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(y0, nb0, c0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(x1, nb1, a1, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(y1, nb1, c1, 0, 0, 0);
+          off = off1 + 4 + ((((k2 + 1) & 3) == 3) ? TZ_QSTR - 16 : 0);
+        }
+        if (k2 < pp) {
+          const double nb0 = -pb[off];
+          a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa[off], nb0, a0, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f64_4x4x4f64(pa2[off], nb0, c0, 0, 0, 0);
+        }
+        if (va) *pc = a0 + a1;
+        if (vb) *pc2 = c0 + c1;
+      }
+      tz_wave_sync();
+    }
+    tz_factor_col(Tz, Hq, dinv, flag, pp, lane, 64);
+    tz_wave_sync();
+  }
+}
+
 // Solve (L L') out = rhs.  Thread t owns row t (nzp <= 256) in a register; wave w owns the 64-row block w.
 // Forward: the blocks are finished one after the other.  Inside a block the 16 tile steps run wave-synchronously (owner
 // quad finishes its 4 unknowns with DPP broadcasts and publishes them in LDS, the other lanes of the SAME wave pick them up:
@@ -570,7 +625,7 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
 __host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit) {
-  return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 10 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX;
+  return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 14 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX;
 }
 
 typedef __attribute__((address_space(4))) const IpmParams* TzKargPtr;
@@ -589,6 +644,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   extern __shared__ double lds[];
   const int b = blockIdx.x;
   const int t = threadIdx.x;
+  const bool wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
   const int nz = p.nz, mi = p.mi, nzp = p.nzp, mip = p.mip;
   const FuseParams& F0 = p.F;
   const bool fused = F0.on != 0;          // closed-loop step in one launch: tube + parameter maps before, recovery + plant after
@@ -607,7 +663,8 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   double* qv = r1v + nzp;
   double* tmpz = qv + nzp;
   double* part = tmpz + nzp;              // 4 * nzp
-  double* vin = part + 4 * nzp;           // mip + 4 : staging of one row vector (w for the Gram, inputs of G' products)
+  double* part2 = part + 4 * nzp;         // 4 * nzp
+  double* vin = part2 + 4 * nzp;           // mip + 4 : staging of one row vector (w for the Gram, inputs of G' products)
   double* red = vin + mip + 4;            // 16
   int* flag = (int*)(red + 16);
   int* kl = (int*)(red + 18);
@@ -732,7 +789,8 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     __syncthreads();
     for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? tz_gemvT_get(part, nzp, c) - qv[c] : 0.0;
     __syncthreads();
-    okf = tz_cholesky(p, Hq, dinv, flag);
+    if (p.chol1) { if (wave0) tz_cholesky_wave(p, Hq, dinv, flag); __syncthreads(); okf = (*flag == 0); }
+    else okf = tz_cholesky(p, Hq, dinv, flag);
     tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
     __syncthreads();
     tz_gemv_G<MAXR>(p, xv, gx_);
@@ -747,32 +805,32 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       TZ_ROWS(k, r) s_[k] = h_[k] - gx_[k] + shift;
     }
   }
-  exact_rd();
   }
   const double sc_d = 1.0 + scq, sc_p = 1.0 + sch;
 
   status = skip ? 3 : (okf ? 1 : 2);
   for (it = 0; it < p.max_iter && status == 1; ++it) {
     TZ_STAMP(PH_ELEM);
-    // residuals: rd is carried along (Newton on a linear residual: rd <- (1 - alpha) rd) and re-evaluated exactly before
-    // convergence is declared; rp = G x + s - h ; mu
-    double nrd = 0, nrp = 0, sl = 0;
-    for (int c = t; c < nz; c += TZ_THREADS) nrd = fmax(nrd, fabs(rdv[c]));
+    // primal residual rp = G x + s - h and complementarity every iteration; the dual residual rd = P x + q + G'lambda is not
+    // carried along at all: the right-hand sides below are written without it, and it is evaluated (exactly) only when rp and
+    // mu already pass the test
+    double nrp = 0, sl = 0, z0 = 0;
     TZ_ROWS(k, r) { rp_[k] = gx_[k] + s_[k] - h_[k]; nrp = fmax(nrp, fabs(rp_[k])); sl += s_[k] * l_[k]; }
-    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(nrd, nrp, sl, red);
+    tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM>(nrp, sl, z0, red);
     const double mu = sl / mi;
-    nrd /= sc_d; nrp /= sc_p;
-    if ((nrd <= p.tol && nrp <= p.tol && mu <= p.mu_tol) || mu <= 1e-3 * p.mu_tol) {
+    nrp /= sc_p;
+    if (!(mu == mu) || !(nrp == nrp) || mu > 1e200) { status = 2; break; }
+    if ((nrp <= p.tol && mu <= p.mu_tol) || mu <= 1e-3 * p.mu_tol) {
       exact_rd();
       double e1 = 0, e2 = 0, e3 = 0;
       for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
       tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(e1, e2, e3, red);
-      nrd = e1 / sc_d;
+      const double nrd = e1 / sc_d;
       TZ_STAMP(PH_GEMVT);
+      if (!(nrd == nrd)) { status = 2; break; }
       if (nrd <= p.tol && nrp <= p.tol && mu <= p.mu_tol) { status = 0; break; }
       if (mu <= 1e-3 * p.mu_tol) { status = (nrd <= 1e3 * p.tol && nrp <= 1e3 * p.tol) ? 0 : 3; break; }
     }
-    if (!(mu == mu) || !(nrd == nrd) || mu > 1e200) { status = 2; break; }
     // Newton matrix.  is = 1/s, il = 1/lambda are the only two divisions per row and iteration.
     TZ_ROWS(k, r) { is_[k] = 1.0 / s_[k]; il_[k] = 1.0 / l_[k]; w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
     __syncthreads();
@@ -780,24 +838,48 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     tz_gram(p, Hq, Pq, vin, kl, (PROF && t == 0) ? acc_ph : nullptr);
     __syncthreads();
     TZ_STAMP(PH_FORM);
-    if (!tz_cholesky(p, Hq, dinv, flag, (PROF && t == 0) ? acc_ph : nullptr)) { status = 2; break; }
-    TZ_STAMP(PH_CHOL);
-    // ---- predictor: rc = s*lam ------------------------------------------------------------------
-    TZ_ROWS(k, r) vin[r] = w_[k] * rp_[k] - l_[k];                    // (-rc + lam rp)/s
+    // ---- predictor (rc = s*lam):  H dx = -(P x + q) - G'(w rp).  The factorisation of H and the two products on the right
+    // are independent: with chol1 wave 0 factors while waves 1-3 form the right-hand side.
+    TZ_ROWS(k, r) vin[r] = w_[k] * rp_[k];
     __syncthreads();
-    TZ_STAMP(PH_ELEM);
-    tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
-    __syncthreads();
-    for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? -rdv[c] - tz_gemvT_get(part, nzp, c) : 0.0;
-    __syncthreads();
-    TZ_STAMP(PH_GEMVT);
+    bool okc;
+    if (p.chol1) {
+      if (wave0) tz_cholesky_wave(p, Hq, dinv, flag);
+      else {
+        tz_gemvT_partial<NCG, 1, 3>(p.G, mi, nzp, vin, part);
+        tz_gemvT_partial<NCG, 1, 3>(p.P, p.nP, nzp, xv, part2);
+      }
+      __syncthreads();
+      okc = (*flag == 0);
+      for (int c = t; c < nzp; c += TZ_THREADS) {
+        const double pxq = (c < nz) ? tz_gemvT_get3(part2, nzp, c) + qv[c] : 0.0;
+        rdv[c] = pxq;                                                   // P x + q, used again by the corrector
+        r1v[c] = (c < nz) ? -pxq - tz_gemvT_get3(part, nzp, c) : 0.0;
+      }
+      __syncthreads();
+      TZ_STAMP(PH_CHOL);
+    } else {
+      tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
+      tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part2);
+      __syncthreads();
+      for (int c = t; c < nzp; c += TZ_THREADS) {
+        const double pxq = (c < nz) ? tz_gemvT_get(part2, nzp, c) + qv[c] : 0.0;
+        rdv[c] = pxq;
+        r1v[c] = (c < nz) ? -pxq - tz_gemvT_get(part, nzp, c) : 0.0;
+      }
+      __syncthreads();
+      TZ_STAMP(PH_GEMVT);
+      okc = tz_cholesky(p, Hq, dinv, flag, (PROF && t == 0) ? acc_ph : nullptr);
+      TZ_STAMP(PH_CHOL);
+    }
+    if (!okc) { status = 2; break; }
     tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
     tz_gemv_G<MAXR>(p, dxv, g_);
     TZ_STAMP(PH_GEMV);
     // step to the boundary: alpha = 1 / max(1, max_i(-dv_i / v_i))
-    double mp = 0.0, md = 0.0, z0 = 0;
+    double mp = 0.0, md = 0.0, z4 = 0;
     TZ_ROWS(k, r) {
       const double ds = -rp_[k] - g_[k];
       const double dl = -l_[k] - w_[k] * ds;
@@ -805,27 +887,27 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       mp = fmax(mp, -ds * is_[k]);
       md = fmax(md, -dl * il_[k]);
     }
-    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(mp, md, z0, red);
+    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(mp, md, z4, red);
     const double ap = 1.0 / fmax(1.0, mp), ad = 1.0 / fmax(1.0, md);
     double muaff = 0, z1 = 0, z2 = 0;
     TZ_ROWS(k, r) muaff += (s_[k] + ap * ds_[k]) * (l_[k] + ad * dl_[k]);
     tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(muaff, z1, z2, red);
     muaff /= mi;
+    const double sfr = (p.sf_gain > 0.0) ? fmin(p.sf_cap, fmax(p.step_frac, 1.0 - p.sf_gain * mu)) : p.step_frac;
     if (fmin(ap, ad) >= p.aff_thr && muaff <= p.aff_mu * mu) {
       // the Newton (predictor) step is already (almost) a full step and kills complementarity: take it, skip the corrector
       const double mmA = fmax(mp, md);
-      const double sfrA = (p.sf_gain > 0.0) ? fmin(p.sf_cap, fmax(p.step_frac, 1.0 - p.sf_gain * mu)) : p.step_frac;
-      const double alphaA = (mmA > sfrA) ? sfrA / mmA : 1.0;
-      for (int c = t; c < nz; c += TZ_THREADS) { xv[c] += alphaA * dxv[c]; rdv[c] *= (1.0 - alphaA); }
+      const double alphaA = (mmA > sfr) ? sfr / mmA : 1.0;
+      for (int c = t; c < nz; c += TZ_THREADS) xv[c] += alphaA * dxv[c];
       TZ_ROWS(k, r) { s_[k] += alphaA * ds_[k]; l_[k] += alphaA * dl_[k]; gx_[k] += alphaA * g_[k]; }
       __syncthreads();
       continue;
     }
     double sigma = muaff / mu; sigma = sigma * sigma * sigma;
-    // ---- corrector: rc = s*lam + dsa*dla - sigma mu -----------------------------------------------
+    // ---- corrector (rc = s*lam + dsa*dla - sigma mu):  H dx = -(P x + q) - G'(lam + (lam rp - rc) / s) -------------------
     TZ_ROWS(k, r) {
       const double rc = s_[k] * l_[k] + ds_[k] * dl_[k] - sigma * mu;
-      vin[r] = (l_[k] * rp_[k] - rc) * is_[k];
+      vin[r] = l_[k] + (l_[k] * rp_[k] - rc) * is_[k];
       ds_[k] = rc;                                  // keep rc for the dl formula
     }
     __syncthreads();
@@ -851,9 +933,8 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     }
     tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(ms, ml, z3, red);
     const double mm = fmax(ms, ml);
-    const double sfr = (p.sf_gain > 0.0) ? fmin(p.sf_cap, fmax(p.step_frac, 1.0 - p.sf_gain * mu)) : p.step_frac;
     const double alpha = (mm * 1.0 > sfr) ? sfr / mm : 1.0;      // min(1, sfr * min_i(-v_i/dv_i))
-    for (int c = t; c < nz; c += TZ_THREADS) { xv[c] += alpha * dxv[c]; rdv[c] *= (1.0 - alpha); }
+    for (int c = t; c < nz; c += TZ_THREADS) xv[c] += alpha * dxv[c];
     TZ_ROWS(k, r) { s_[k] += alpha * ds_[k]; l_[k] += alpha * dl_[k]; gx_[k] += alpha * g_[k]; }
     __syncthreads();
   }

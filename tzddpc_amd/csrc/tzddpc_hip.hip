@@ -106,6 +106,7 @@ struct tz_problem {
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
   double warm_floor = 1e-8, warm_gain = 1.0, warm_cold = 0.0, sf_gain = 0.0, sf_cap = 1.0, mu_factor = 0.1, aff_thr = 0.99, aff_mu = 1e-3;
   bool warm_enabled = true;
+  bool chol1 = false;          // single-wave Cholesky overlapped with the predictor's G' product (Tz <= 16; TZ_CHOL1=0 disables)
   bool ksplit = false;         // Gram by k-split (Tz <= TZ_KS_TZ; TZ_KSPLIT=0 keeps the item plan)
   bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_FUSE=0: four kernels per step, same arithmetic)
   int maxr = 1, ncg = 1;
@@ -187,7 +188,7 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac; ip.mu_tol = p->tol * p->mu_factor;
   ip.prof = p->prof ? p->prof_buf.p : nullptr;
   ip.work = p->timing ? p->work_buf.p : nullptr;
-  ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0;
+  ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0; ip.chol1 = p->chol1 ? 1 : 0;
   ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
   ip.warm_gain = p->warm_gain; ip.warm_cold = p->warm_cold; ip.sf_gain = p->sf_gain; ip.sf_cap = p->sf_cap; ip.aff_thr = p->aff_thr; ip.aff_mu = p->aff_mu;
   ip.prev_status = warm ? p->prev_status.p : nullptr;
@@ -239,6 +240,7 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
   {
     Timer tm(p, K_IPM);
     IpmParams ip = ipm_params(p, B, d_status, d_iters, warm, track_prev);
+    if (d_active) ip.mu_tol *= 1e-3;      // active-set readout (slack < multiplier) needs the complementarity products well below the slacks
     hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, st, ip);
   }
   {
@@ -439,6 +441,8 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   TZ_HIP(p->act_scale.upload(d->act_scale, (size_t)mi));
 
   p->ksplit = (p->Tz <= TZ_KS_TZ);
+  p->chol1 = (p->Tz <= 16);
+  if (const char* e = getenv("TZ_CHOL1")) { if (e[0] == '0') p->chol1 = false; }
   if (const char* e = getenv("TZ_KSPLIT")) { if (e[0] == '0') p->ksplit = false; }
   p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist, p->ntheta, p->ksplit ? 1 : 0) * sizeof(double);
   if (mi > 4 * TZ_THREADS) TZ_FAIL(TZ_ERR_UNSUPPORTED, "mi=%d > %d inequality rows not supported by tz_ipm_kernel", mi, 4 * TZ_THREADS);
