@@ -39,6 +39,7 @@ struct IpmParams {
   int max_iter; double tol, reg, step_frac;
   double mu_tol;              // complementarity target (<= tol): the distance to the solution of a degenerate problem goes like sqrt(mu)
   int warm_steps;             // multi-step launches: step k+1 starts from the solution of step k
+  int ntube;                  // doubles of tube tables kept in LDS by fused launches: (pmax + 1) n n + pmax (n + m) n
   int chol1;                  // Tz <= 16: one wave factors H while the other three form the predictor's right-hand side
   int ksplit;                 // Gram by tz_form_H_ksplit (Tz <= TZ_KS_TZ) instead of the item plan
   int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
@@ -624,8 +625,8 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
 }
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
-__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit) {
-  return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 14 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX;
+__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit, int ntube) {
+  return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 14 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX + (size_t)ntube;
 }
 
 typedef __attribute__((address_space(4))) const IpmParams* TzKargPtr;
@@ -670,7 +671,8 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   int* kl = (int*)(red + 18);
   double* thl = red + 18 + (p.nklist + 1) / 2;      // theta of this trajectory (fused step only)
   double* stl = thl + p.F.ntheta;                   // fused: closed-loop state [x | xbar | e] (3 TZ_NMAX doubles)
-  double* Pq = stl + 3 * TZ_NMAX;                   // ksplit: P + reg I in the quad layout of Hq (lower tiles)
+  double* tbl = stl + 3 * TZ_NMAX;                  // fused: C_K powers and the tube resolvent (copied once per launch)
+  double* Pq = tbl + p.ntube;                       // ksplit: P + reg I in the quad layout of Hq (lower tiles)
 
   // rows owned by this thread
   double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR], w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR], is_[MAXR], il_[MAXR];
@@ -690,6 +692,10 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     }
   }
   else for (int i = t; i < p.nklist; i += TZ_THREADS) kl[i] = p.klist[i];
+  if (fused) {
+    const int n1 = (F0.tube.pmax + 1) * F0.tube.n * F0.tube.n;
+    for (int i = t; i < p.ntube; i += TZ_THREADS) tbl[i] = (i < n1) ? F0.tube.CKpow[i] : F0.tube.T[i - n1];
+  }
   if (fused && t < F0.fin.n) {                    // closed-loop state [x | xbar | e] stays in LDS for all steps of this launch
     stl[t] = F0.plant.x[(size_t)b * F0.fin.n + t];
     stl[F0.fin.n + t] = F0.plant.xbar[(size_t)b * F0.fin.n + t];
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the cold start point
   if (fused) {
     if (t == 0) { flag[0] = 0; flag[1] = 0; }
-    tz_tube_block(F.tube, stl + F.fin.n, stl + 2 * F.fin.n, Hq, thl, t, TZ_THREADS);       // the factor storage is free until the first Gram
+    tz_tube_block(F.tube, tbl, tbl + (F.tube.pmax + 1) * F.tube.n * F.tube.n, stl + F.fin.n, stl + 2 * F.fin.n, Hq, thl, t, TZ_THREADS);       // the factor storage is free until the first Gram
     __syncthreads();
     for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? csr_row(F.qmap, c, thl) : 0.0; if (src != 2) xv[c] = 0.0; }
     int bad = 0;
@@ -809,6 +815,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   const double sc_d = 1.0 + scq, sc_p = 1.0 + sch;
 
   status = skip ? 3 : (okf ? 1 : 2);
+  bool px_in_part = false;                  // `part` holds the partial sums of P x for the final x (left there by exact_rd)
   for (it = 0; it < p.max_iter && status == 1; ++it) {
     TZ_STAMP(PH_ELEM);
     // primal residual rp = G x + s - h and complementarity every iteration; the dual residual rd = P x + q + G'lambda is not
@@ -828,8 +835,8 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       const double nrd = e1 / sc_d;
       TZ_STAMP(PH_GEMVT);
       if (!(nrd == nrd)) { status = 2; break; }
-      if (nrd <= p.tol && nrp <= p.tol && mu <= p.mu_tol) { status = 0; break; }
-      if (mu <= 1e-3 * p.mu_tol) { status = (nrd <= 1e3 * p.tol && nrp <= 1e3 * p.tol) ? 0 : 3; break; }
+      if (nrd <= p.tol && nrp <= p.tol && mu <= p.mu_tol) { status = 0; px_in_part = true; break; }
+      if (mu <= 1e-3 * p.mu_tol) { status = (nrd <= 1e3 * p.tol && nrp <= 1e3 * p.tol) ? 0 : 3; px_in_part = true; break; }
     }
     // Newton matrix.  is = 1/s, il = 1/lambda are the only two divisions per row and iteration.
     TZ_ROWS(k, r) { is_[k] = 1.0 / s_[k]; il_[k] = 1.0 / l_[k]; w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
@@ -957,7 +964,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     const int n = F.fin.n, m = F.fin.m, N = F.fin.N, nv = N * m;
     const double* x0 = stl + n;                         // nominal state this step started from
     __syncthreads();
-    tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
+    if (!px_in_part) tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
     for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = F.fin.Dz[c] * xv[c];
     __syncthreads();
     double acc = 0.0, z1 = 0.0, z2 = 0.0;
@@ -973,7 +980,8 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       if (F.plant.sticky && F.plant.sticky[b] == 0 && status != 0) F.plant.sticky[b] = status;
     }
     if (F.fin.v) for (int c = t; c < nv; c += TZ_THREADS) F.fin.v[(size_t)b * nv + c] = dxv[c];
-    for (int r = t; r < (N + 1) * n; r += TZ_THREADS) {
+    const int rlo = F.fin.xbar ? 0 : n, rhi = F.fin.xbar ? (N + 1) * n : 2 * n;      // only xbar[1] feeds the next step
+    for (int r = rlo + t; r < rhi; r += TZ_THREADS) {
       double a = 0.0;
       for (int j = 0; j < n; ++j) a += F.fin.Phi[(size_t)r * n + j] * x0[j];
       const double* g = F.fin.Gam + (size_t)r * nv;

@@ -23,9 +23,10 @@
 #define TZ_NMAX 8          // max dim_x supported by the tube kernel's register arrays
 #define TZ_MMAX 4
 
+// Affine map rows over theta in ELL form: entry e of row r at [e * rows + r] (coalesced over rows), W entries per row, rows
+// with fewer non-zeros padded with (0.0, column 0).  No row pointers: every load of a row is independent of the others.
 struct TzCsr {
-  int rows;
-  const int* ptr;
+  int rows, W;
   const int* col;
   const double* val;
   const double* c0;
@@ -54,10 +55,10 @@ struct TubeParams {
 #define TZ_PMAX 128        // highest supported power of M_K
 // All nt threads of the workgroup (tid) work on trajectory b.  aL: pmax * n doubles of LDS scratch; th: ntheta doubles (LDS or
 // global).  Contains one workgroup barrier; the caller adds another before th is read by other threads.
-__device__ inline void tz_tube_block(const TubeParams& p, const double* xbar0, const double* e0, double* aL, double* th, int tid, int nt) {
+__device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, const double* Ttab, const double* xbar0, const double* e0, double* aL, double* th, int tid, int nt) {
   const int n = p.n, m = p.m, hs = 2 * n + m;
   for (int e = tid; e < p.pmax * n; e += nt) {
-    const double* M = p.CKpow + (size_t)e * n;            // row i of C_K^l with e = l n + i
+    const double* M = CKpow + (size_t)e * n;              // row i of C_K^l with e = l n + i
     double a = 0.0;
     for (int j = 0; j < n; ++j) a += M[j] * e0[j];
     aL[e] = fabs(a);
@@ -68,11 +69,11 @@ __device__ inline void tz_tube_block(const TubeParams& p, const double* xbar0, c
     const int k = e / hs, idx = e % hs, pw = p.power[k];
     double a = 0.0;
     if (idx < n) {
-      const double* M = p.CKpow + ((size_t)pw * n + idx) * n;
+      const double* M = CKpow + ((size_t)pw * n + idx) * n;
       for (int j = 0; j < n; ++j) a += M[j] * e0[j];
     } else {
       const int comp = idx - n;
-      const double* T = p.T + ((size_t)(pw - 1) * (n + m) + comp) * n;     // walks down as l goes up
+      const double* T = Ttab + ((size_t)(pw - 1) * (n + m) + comp) * n;    // walks down as l goes up
       const double* al = aL;
 #pragma unroll 4
       for (int l = 0; l < pw; ++l, T -= (size_t)(n + m) * n, al += n)
@@ -85,7 +86,7 @@ __device__ inline void tz_tube_block(const TubeParams& p, const double* xbar0, c
 __global__ __launch_bounds__(64) void tz_tube_kernel(TubeParams p) {
   __shared__ double aL[TZ_PMAX * TZ_NMAX];
   const int b = blockIdx.x;
-  tz_tube_block(p, p.xbar0 + (size_t)b * p.n, p.e0 + (size_t)b * p.n, aL, p.theta + (size_t)b * p.ntheta, threadIdx.x, 64);
+  tz_tube_block(p, p.CKpow, p.T, p.xbar0 + (size_t)b * p.n, p.e0 + (size_t)b * p.n, aL, p.theta + (size_t)b * p.ntheta, threadIdx.x, 64);
   if (threadIdx.x == 0) p.prestatus[b] = 0;
 }
 
@@ -101,9 +102,15 @@ struct AffineParams {
   int* prestatus;           // B (zeroed before launch); set to 1 when a parameter row is violated
 };
 
+#define TZ_ELL_REG 8
 __device__ inline double csr_row(const TzCsr& M, int r, const double* th) {
   double acc = M.c0[r];
-  for (int e = M.ptr[r]; e < M.ptr[r + 1]; ++e) acc += M.val[e] * th[M.col[e]];
+  double v[TZ_ELL_REG]; int c[TZ_ELL_REG];
+#pragma unroll
+  for (int e = 0; e < TZ_ELL_REG; ++e) { v[e] = 0.0; c[e] = 0; if (e < M.W) { v[e] = M.val[(size_t)e * M.rows + r]; c[e] = M.col[(size_t)e * M.rows + r]; } }
+#pragma unroll
+  for (int e = 0; e < TZ_ELL_REG; ++e) if (e < M.W) acc += v[e] * th[c[e]];
+  for (int e = TZ_ELL_REG; e < M.W; ++e) acc += M.val[(size_t)e * M.rows + r] * th[M.col[(size_t)e * M.rows + r]];
   return acc;
 }
 

@@ -43,22 +43,23 @@ struct DevBuf {
   hipError_t upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
 };
 
-struct DevCsr {
-  DevBuf<int> ptr, col;
+struct DevCsr {          // device copy of a tz_affmap (CSR in the ABI) re-laid out as ELL, see TzCsr
+  DevBuf<int> col;
   DevBuf<double> val, c0;
-  int rows = 0;
+  int rows = 0, W = 1;
   hipError_t upload(const tz_affmap& m) {
-    rows = m.rows;
-    std::vector<int> p0(1, 0);
-    const int* ptr_src = m.rows ? m.ptr : p0.data();
+    rows = m.rows; W = 1;
+    for (int r = 0; r < m.rows; ++r) W = std::max(W, m.ptr[r + 1] - m.ptr[r]);
+    std::vector<int> ce((size_t)W * std::max(rows, 1), 0);
+    std::vector<double> ve((size_t)W * std::max(rows, 1), 0.0);
+    for (int r = 0; r < m.rows; ++r)
+      for (int e = m.ptr[r]; e < m.ptr[r + 1]; ++e) { ce[(size_t)(e - m.ptr[r]) * rows + r] = m.col[e]; ve[(size_t)(e - m.ptr[r]) * rows + r] = m.val[e]; }
     hipError_t e;
-    if ((e = ptr.upload(ptr_src, (size_t)m.rows + 1)) != hipSuccess) return e;
-    int nnz = m.rows ? m.ptr[m.rows] : 0;
-    if ((e = col.upload(m.col, (size_t)nnz)) != hipSuccess) return e;
-    if ((e = val.upload(m.val, (size_t)nnz)) != hipSuccess) return e;
+    if ((e = col.upload(ce)) != hipSuccess) return e;
+    if ((e = val.upload(ve)) != hipSuccess) return e;
     return c0.upload(m.c0, (size_t)m.rows);
   }
-  TzCsr view() const { return TzCsr{rows, ptr.p, col.p, val.p, c0.p}; }
+  TzCsr view() const { return TzCsr{rows, W, col.p, val.p, c0.p}; }
 };
 
 enum { K_TUBE = 0, K_IPM = 1, K_FINISH = 2, K_PLANT = 3, K_COUNT = 4 };
@@ -106,6 +107,7 @@ struct tz_problem {
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
   double warm_floor = 1e-8, warm_gain = 1.0, warm_cold = 0.0, sf_gain = 0.0, sf_cap = 1.0, mu_factor = 0.1, aff_thr = 0.99, aff_mu = 1e-3;
   bool warm_enabled = true;
+  int ntube = 0;
   bool chol1 = false;          // single-wave Cholesky overlapped with the predictor's G' product (Tz <= 16; TZ_CHOL1=0 disables)
   bool ksplit = false;         // Gram by k-split (Tz <= TZ_KS_TZ; TZ_KSPLIT=0 keeps the item plan)
   bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_FUSE=0: four kernels per step, same arithmetic)
@@ -188,7 +190,7 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac; ip.mu_tol = p->tol * p->mu_factor;
   ip.prof = p->prof ? p->prof_buf.p : nullptr;
   ip.work = p->timing ? p->work_buf.p : nullptr;
-  ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0; ip.chol1 = p->chol1 ? 1 : 0;
+  ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0; ip.chol1 = p->chol1 ? 1 : 0; ip.ntube = p->ntube;
   ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
   ip.warm_gain = p->warm_gain; ip.warm_cold = p->warm_cold; ip.sf_gain = p->sf_gain; ip.sf_cap = p->sf_cap; ip.aff_thr = p->aff_thr; ip.aff_mu = p->aff_mu;
   ip.prev_status = warm ? p->prev_status.p : nullptr;
@@ -215,7 +217,7 @@ int launch_step_fused(tz_problem* p, int B, double* d_x, double* d_xbar, double*
   F.qmap = p->q.view(); F.hmap = p->h.view(); F.parmap = p->par.view(); F.par_lo = p->par_lo.p; F.par_hi = p->par_hi.p;
   F.fin = FinishParams{B, p->n, p->m, p->N, p->nz, p->mi, p->nzp, p->nc_rows, p->P.p, p->Dz.p, p->Phi.p, p->Gam.p,
                        p->r1.p, p->R2.p, p->r0, p->cost_scale, p->row_of.p, p->act_scale.p, d_xbar, nullptr, nullptr, nullptr, nullptr,
-                       d_status, p->v.p, p->xbar.p, d_cost, nullptr, cost_stride};
+                       d_status, nsteps > 1 ? nullptr : p->v.p, nsteps > 1 ? nullptr : p->xbar.p, d_cost, nullptr, cost_stride};
   F.plant = PlantParams{B, p->n, p->m, p->N, p->K.p, d_A, d_Bm, nullptr, nullptr, d_w, w_stride, d_status, d_x, d_xbar, d_e,
                         d_u, u_stride, d_xout, x_stride, d_sticky};
   hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, p->stream, ip);
@@ -441,10 +443,11 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   TZ_HIP(p->act_scale.upload(d->act_scale, (size_t)mi));
 
   p->ksplit = (p->Tz <= TZ_KS_TZ);
+  p->ntube = (d->pmax + 1) * d->n * d->n + std::max(d->pmax, 1) * (d->n + d->m) * d->n;
   p->chol1 = (p->Tz <= 16);
   if (const char* e = getenv("TZ_CHOL1")) { if (e[0] == '0') p->chol1 = false; }
   if (const char* e = getenv("TZ_KSPLIT")) { if (e[0] == '0') p->ksplit = false; }
-  p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist, p->ntheta, p->ksplit ? 1 : 0) * sizeof(double);
+  p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist, p->ntheta, p->ksplit ? 1 : 0, p->ntube) * sizeof(double);
   if (mi > 4 * TZ_THREADS) TZ_FAIL(TZ_ERR_UNSUPPORTED, "mi=%d > %d inequality rows not supported by tz_ipm_kernel", mi, 4 * TZ_THREADS);
   if (p->lds_bytes > 160 * 1024)
     TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
