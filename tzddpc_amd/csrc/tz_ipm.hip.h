@@ -20,6 +20,15 @@
 #define TZ_QSTR (4 * TZ_QROW)
 struct IpmItem { int I0, q0, nq, kptr, klen; };
 
+// G in balanced "lane-ELL" form for the matrix-vector products (built by the host, tz_problem_create): the non-zeros of every
+// output (a row of G for G x, a column for G'v) are dealt to as many consecutive virtual lanes as it takes to give every lane
+// at most L entries; entry e of virtual lane v is at [(pass * L + e) * NL + lane] with v = pass * NL + lane (NL = 256 for G x,
+// 192 for G'v: waves 1-3, wave 0 does something else meanwhile).  Every lane walks L (value, index) pairs -- coalesced,
+// no zeros fetched, equal work per lane -- and leaves one partial sum in LDS; the owner of an output adds its lanes' partial
+// sums in a fixed order (seg[o] = first lane | lanes << 16).  G is fetched once per product at ~10 B per non-zero instead of
+// 8 B per entry of the dense matrix (and of the 26 idle lanes of a 38-wide row).
+struct TzEll { int L, VL; const double* val; const unsigned short* idx; const int* seg; };
+
 struct IpmParams {
   int B, nz, mi, nzp, mip, Tz, Kc, nquads, nklist, nP;   // nP: rows of P beyond which P is zero
   const double* P;       // nzp x nzp
@@ -29,6 +38,7 @@ struct IpmParams {
   const IpmItem* items;  // Gram work items, grouped per wave
   const int* item_ptr;   // TZ_NWAVES + 1
   const int* klist;
+  TzEll eg, et;          // G x (outputs = rows) and G'v (outputs = columns)
   const int* smask;      // ksplit: per super-step (16 rows of G) bit J set when tile column J has a non-zero; smask[S] = 0
   const double* q; const double* h;
   const int* prestatus;
@@ -39,6 +49,7 @@ struct IpmParams {
   int max_iter; double tol, reg, step_frac;
   double mu_tol;              // complementarity target (<= tol): the distance to the solution of a degenerate problem goes like sqrt(mu)
   int warm_steps;             // multi-step launches: step k+1 starts from the solution of step k
+  int nell;                   // max(eg.VL, et.VL)
   int ntube;                  // doubles of tube tables kept in LDS by fused launches: (pmax + 1) n n + pmax (n + m) n
   int chol1;                  // Tz <= 16: one wave factors H while the other three form the predictor's right-hand side
   int ksplit;                 // Gram by tz_form_H_ksplit (Tz <= TZ_KS_TZ) instead of the item plan
@@ -158,6 +169,60 @@ __device__ inline double tz_gemvT_get(const double* part, int nzp, int c) {
 }
 __device__ inline double tz_gemvT_get3(const double* part, int nzp, int c) {
   return (part[c] + part[nzp + c]) + part[2 * nzp + c];
+}
+
+// out[k] = (G in)_r for the rows r = t + 256 k this thread owns; `in` (nz entries) and pl (eg.VL doubles) in LDS.
+template <int MAXR>
+__device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double* pl, const int (&rseg)[MAXR], double (&out)[MAXR]) {
+  const int t = threadIdx.x, L = p.eg.L;
+  __syncthreads();                                   // pl may still be read by the owners of the previous product
+  for (int v0 = 0; v0 < p.eg.VL; v0 += TZ_THREADS) {
+    const double* val = p.eg.val + (size_t)v0 * L + t;
+    const unsigned short* idx = p.eg.idx + (size_t)v0 * L + t;
+    double a0 = 0.0, a1 = 0.0;
+    int e = 0;
+    for (; e + 3 < L; e += 4) {
+      const double x0 = val[(size_t)e * TZ_THREADS], x1 = val[(size_t)(e + 1) * TZ_THREADS], x2 = val[(size_t)(e + 2) * TZ_THREADS], x3 = val[(size_t)(e + 3) * TZ_THREADS];
+      const int i0 = idx[(size_t)e * TZ_THREADS], i1 = idx[(size_t)(e + 1) * TZ_THREADS], i2 = idx[(size_t)(e + 2) * TZ_THREADS], i3 = idx[(size_t)(e + 3) * TZ_THREADS];
+      a0 += x0 * in[i0]; a1 += x1 * in[i1]; a0 += x2 * in[i2]; a1 += x3 * in[i3];
+    }
+    for (; e < L; ++e) a0 += val[(size_t)e * TZ_THREADS] * in[idx[(size_t)e * TZ_THREADS]];
+    pl[v0 + t] = a0 + a1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < MAXR; ++k) {
+    double a = 0.0;
+    const int first = rseg[k] & 0xffff, cnt = rseg[k] >> 16;
+    for (int j = 0; j < cnt; ++j) a += pl[first + j];
+    out[k] = a;
+  }
+}
+
+// Partial sums of G'in by the 192 threads of waves 1-3 (the caller keeps wave 0 out); `in` (mi entries), pl (et.VL doubles) in
+// LDS.  After the next workgroup barrier tz_ell_colsum(pl, cseg) is column c's value for the thread holding cseg = et.seg[c].
+__device__ inline void tz_ell_gemvT_part(const IpmParams& p, const double* in, double* pl) {
+  constexpr int NL = TZ_THREADS - 64;
+  const int l = threadIdx.x - 64, L = p.et.L;
+  for (int v0 = 0; v0 < p.et.VL; v0 += NL) {
+    const double* val = p.et.val + (size_t)v0 * L + l;
+    const unsigned short* idx = p.et.idx + (size_t)v0 * L + l;
+    double a0 = 0.0, a1 = 0.0;
+    int e = 0;
+    for (; e + 3 < L; e += 4) {
+      const double x0 = val[(size_t)e * NL], x1 = val[(size_t)(e + 1) * NL], x2 = val[(size_t)(e + 2) * NL], x3 = val[(size_t)(e + 3) * NL];
+      const int i0 = idx[(size_t)e * NL], i1 = idx[(size_t)(e + 1) * NL], i2 = idx[(size_t)(e + 2) * NL], i3 = idx[(size_t)(e + 3) * NL];
+      a0 += x0 * in[i0]; a1 += x1 * in[i1]; a0 += x2 * in[i2]; a1 += x3 * in[i3];
+    }
+    for (; e < L; ++e) a0 += val[(size_t)e * NL] * in[idx[(size_t)e * NL]];
+    pl[v0 + l] = a0 + a1;
+  }
+}
+__device__ inline double tz_ell_colsum(const double* pl, int cseg) {
+  double a = 0.0;
+  const int first = cseg & 0xffff, cnt = cseg >> 16;
+  for (int j = 0; j < cnt; ++j) a += pl[first + j];
+  return a;
 }
 
 // Gram matrix  H = P + G' diag(w) G + reg I  into LDS quads, by v_mfma_f64_4x4x4 (blk = 4 column tiles).
@@ -625,8 +690,8 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
 }
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
-__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit, int ntube) {
-  return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 14 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX + (size_t)ntube;
+__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit, int ntube, int nell) {
+  return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 14 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX + (size_t)ntube + (size_t)nell;
 }
 
 typedef __attribute__((address_space(4))) const IpmParams* TzKargPtr;
@@ -671,12 +736,17 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   int* kl = (int*)(red + 18);
   double* thl = red + 18 + (p.nklist + 1) / 2;      // theta of this trajectory (fused step only)
   double* stl = thl + p.F.ntheta;                   // fused: closed-loop state [x | xbar | e] (3 TZ_NMAX doubles)
-  double* tbl = stl + 3 * TZ_NMAX;                  // fused: C_K powers and the tube resolvent (copied once per launch)
+  double* pl = stl + 3 * TZ_NMAX;                   // partial sums of the lane-ELL products (nell doubles)
+  double* tbl = pl + p.nell;                  // fused: C_K powers and the tube resolvent (copied once per launch)
   double* Pq = tbl + p.ntube;                       // ksplit: P + reg I in the quad layout of Hq (lower tiles)
 
   // rows owned by this thread
   double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR], w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR], is_[MAXR], il_[MAXR];
 #define TZ_ROWS(k, r) _Pragma("unroll") for (int k = 0; k < MAXR; ++k) if (const int r = t + TZ_THREADS * k; r < mi)
+  int rseg_[MAXR];                                   // lanes of the G x product that carry this thread's rows
+#pragma unroll
+  for (int k = 0; k < MAXR; ++k) { const int r = t + TZ_THREADS * k; rseg_[k] = (r < mi) ? p.eg.seg[r] : 0; }
+  const int cseg = (t < nz) ? p.et.seg[t] : 0;       // lanes of the G'v product that carry column t
 
   // ---- once per launch: constants of the problem into LDS, closed-loop state of the trajectory -------------------------
   if (p.ksplit) {
@@ -749,13 +819,10 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   auto exact_rd = [&]() {
     TZ_ROWS(k, r) vin[r] = l_[k];
     __syncthreads();
-    tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
+    if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part);     // P x by wave 0 (stays in `part` for the objective)
+    else tz_ell_gemvT_part(p, vin, pl);                                   // G'lambda by waves 1-3
     __syncthreads();
-    for (int c = t; c < nzp; c += TZ_THREADS) rdv[c] = (c < nz) ? tz_gemvT_get(part, nzp, c) + qv[c] : 0.0;
-    __syncthreads();
-    tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
-    __syncthreads();
-    for (int c = t; c < nz; c += TZ_THREADS) rdv[c] += tz_gemvT_get(part, nzp, c);
+    if (t < nzp) rdv[t] = (t < nz) ? (tz_ell_colsum(pl, cseg) + qv[t]) + part[t] : 0.0;
     __syncthreads();
   };
 
@@ -767,8 +834,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     // ---- warm start: previous (x, lambda) of this trajectory, slacks re-derived for the new h and pushed into the cone
     // by at least the amount the old point violates the new rows; a point that is too far outside starts cold instead
     if (src == 1) { for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + c]; TZ_ROWS(k, r) l_[k] = p.lam[(size_t)b * mi + r]; }
-    __syncthreads();
-    tz_gemv_G<MAXR>(p, xv, gx_);
+    tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
     double viol = 0.0, zv1 = 0.0, zv2 = 0.0;
     TZ_ROWS(k, r) viol = fmax(viol, gx_[k] - h_[k]);
     tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, zv1, zv2, red);
@@ -791,15 +857,14 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     __syncthreads();
     TZ_ROWS(k, r) vin[r] = h_[k];
     __syncthreads();
-    tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
+    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
     __syncthreads();
-    for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? tz_gemvT_get(part, nzp, c) - qv[c] : 0.0;
+    if (t < nzp) r1v[t] = (t < nz) ? tz_ell_colsum(pl, cseg) - qv[t] : 0.0;
     __syncthreads();
     if (p.chol1) { if (wave0) tz_cholesky_wave(p, Hq, dinv, flag); __syncthreads(); okf = (*flag == 0); }
     else okf = tz_cholesky(p, Hq, dinv, flag);
     tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
-    __syncthreads();
-    tz_gemv_G<MAXR>(p, xv, gx_);
+    tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
   }
   {
     double rmin = 1e300;
@@ -853,7 +918,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     if (p.chol1) {
       if (wave0) tz_cholesky_wave(p, Hq, dinv, flag);
       else {
-        tz_gemvT_partial<NCG, 1, 3>(p.G, mi, nzp, vin, part);
+        tz_ell_gemvT_part(p, vin, pl);
         tz_gemvT_partial<NCG, 1, 3>(p.P, p.nP, nzp, xv, part2);
       }
       __syncthreads();
@@ -861,18 +926,18 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       for (int c = t; c < nzp; c += TZ_THREADS) {
         const double pxq = (c < nz) ? tz_gemvT_get3(part2, nzp, c) + qv[c] : 0.0;
         rdv[c] = pxq;                                                   // P x + q, used again by the corrector
-        r1v[c] = (c < nz) ? -pxq - tz_gemvT_get3(part, nzp, c) : 0.0;
+        r1v[c] = (c < nz) ? -pxq - tz_ell_colsum(pl, cseg) : 0.0;
       }
       __syncthreads();
       TZ_STAMP(PH_CHOL);
     } else {
-      tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
-      tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part2);
+      if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part2);
+      else tz_ell_gemvT_part(p, vin, pl);
       __syncthreads();
       for (int c = t; c < nzp; c += TZ_THREADS) {
-        const double pxq = (c < nz) ? tz_gemvT_get(part2, nzp, c) + qv[c] : 0.0;
+        const double pxq = (c < nz) ? part2[c] + qv[c] : 0.0;
         rdv[c] = pxq;
-        r1v[c] = (c < nz) ? -pxq - tz_gemvT_get(part, nzp, c) : 0.0;
+        r1v[c] = (c < nz) ? -pxq - tz_ell_colsum(pl, cseg) : 0.0;
       }
       __syncthreads();
       TZ_STAMP(PH_GEMVT);
@@ -883,7 +948,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
-    tz_gemv_G<MAXR>(p, dxv, g_);
+    tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
     TZ_STAMP(PH_GEMV);
     // step to the boundary: alpha = 1 / max(1, max_i(-dv_i / v_i))
     double mp = 0.0, md = 0.0, z4 = 0;
@@ -919,15 +984,15 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     }
     __syncthreads();
     TZ_STAMP(PH_ELEM);
-    tz_gemvT_partial<NCG>(p.G, mi, nzp, vin, part);
+    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
     __syncthreads();
-    for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? -rdv[c] - tz_gemvT_get(part, nzp, c) : 0.0;
+    for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? -rdv[c] - tz_ell_colsum(pl, cseg) : 0.0;
     __syncthreads();
     TZ_STAMP(PH_GEMVT);
     tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
-    tz_gemv_G<MAXR>(p, dxv, g_);
+    tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
     TZ_STAMP(PH_GEMV);
     double ms = 0.0, ml = 0.0, z3 = 0;
     TZ_ROWS(k, r) {
@@ -968,7 +1033,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = F.fin.Dz[c] * xv[c];
     __syncthreads();
     double acc = 0.0, z1 = 0.0, z2 = 0.0;
-    for (int c = t; c < nz; c += TZ_THREADS) acc += xv[c] * (0.5 * tz_gemvT_get(part, nzp, c) + qv[c]);
+    for (int c = t; c < nz; c += TZ_THREADS) acc += xv[c] * (0.5 * (px_in_part ? part[c] : tz_gemvT_get(part, nzp, c)) + qv[c]);
     tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(acc, z1, z2, red);
     if (t == 0) {
       double r = F.fin.r0;

@@ -43,6 +43,42 @@ struct DevBuf {
   hipError_t upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
 };
 
+// Balanced lane-ELL of a sparse matrix for the matrix-vector products of tz_ipm_kernel (TzEll in tz_ipm.hip.h).
+// outs[o] = (index, value) pairs of output o; NL physical lanes per pass; the virtual lane count VL is a multiple of NL.
+struct DevEll {
+  DevBuf<double> val; DevBuf<unsigned short> idx; DevBuf<int> seg;
+  int L = 1, VL = 0;
+  hipError_t build(const std::vector<std::vector<std::pair<int, double>>>& outs, int NL, int VLwant) {
+    VL = ((std::max(VLwant, 1) + NL - 1) / NL) * NL;
+    size_t nnz = 0; size_t longest = 1;
+    for (auto& o : outs) { nnz += o.size(); longest = std::max(longest, o.size()); }
+    for (L = 1; L <= (int)longest; ++L) {
+      size_t lanes = 0;
+      for (auto& o : outs) lanes += (o.size() + L - 1) / L;
+      if (lanes <= (size_t)VL) break;
+    }
+    std::vector<double> v((size_t)VL * L, 0.0);
+    std::vector<unsigned short> ix((size_t)VL * L, 0);
+    std::vector<int> sg(std::max<size_t>(outs.size(), 1), 0);
+    int lane = 0;
+    for (size_t o = 0; o < outs.size(); ++o) {
+      const int cnt = (int)((outs[o].size() + L - 1) / L);
+      sg[o] = lane | (cnt << 16);
+      for (size_t e = 0; e < outs[o].size(); ++e) {
+        const int vl = lane + (int)(e / L), slot = (int)(e % L);
+        const size_t pos = ((size_t)(vl / NL) * L + slot) * NL + (vl % NL);
+        v[pos] = outs[o][e].second; ix[pos] = (unsigned short)outs[o][e].first;
+      }
+      lane += cnt;
+    }
+    hipError_t e;
+    if ((e = val.upload(v)) != hipSuccess) return e;
+    if ((e = idx.upload(ix)) != hipSuccess) return e;
+    return seg.upload(sg);
+  }
+  TzEll view() const { return TzEll{L, VL, val.p, idx.p, seg.p}; }
+};
+
 struct DevCsr {          // device copy of a tz_affmap (CSR in the ABI) re-laid out as ELL, see TzCsr
   DevBuf<int> col;
   DevBuf<double> val, c0;
@@ -85,6 +121,8 @@ struct tz_problem {
   DevBuf<int> power, row_of, klist, item_ptr, smask;
   DevBuf<IpmItem> items;
   DevCsr q, h, par;
+  DevEll eg, et;
+  int nell = 0;
   size_t lds_bytes = 0;
   int64_t mfma_gram = 0, mfma_chol = 0, mfma_issued = 0;
   // workspace (capacity Bcap)
@@ -184,7 +222,7 @@ void drain_timing(tz_problem* p) {
 IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool warm, bool track_prev) {
   IpmParams ip{};
   ip.B = B; ip.nz = p->nz; ip.mi = p->mi; ip.nzp = p->nzp; ip.mip = p->mip; ip.Tz = p->Tz; ip.Kc = p->Kc; ip.nquads = p->nquads;
-  ip.P = p->P.p; ip.G = p->G.p; ip.Gt = p->Gt.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p; ip.smask = p->smask.p;
+  ip.P = p->P.p; ip.G = p->G.p; ip.Gt = p->Gt.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p; ip.smask = p->smask.p; ip.eg = p->eg.view(); ip.et = p->et.view(); ip.nell = p->nell;
   ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
   ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
   ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac; ip.mu_tol = p->tol * p->mu_factor;
@@ -384,6 +422,17 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
     for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) if (G[(size_t)r * nzp + c] != 0.0) sm[r >> 4] |= 1 << (c >> 2);
     TZ_HIP(p->smask.upload(sm));
   }
+  {
+    std::vector<std::vector<std::pair<int, double>>> byrow((size_t)mi), bycol((size_t)nz);
+    for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) {
+      const double v = G[(size_t)r * nzp + c];
+      if (v != 0.0) { byrow[r].push_back({c, v}); bycol[c].push_back({r, v}); }
+    }
+    // G x: twice as many virtual lanes as rows, so the long rows can be cut up;  G'v: the 192 lanes of waves 1-3 per pass
+    TZ_HIP(p->eg.build(byrow, TZ_THREADS, 2 * mi));
+    TZ_HIP(p->et.build(bycol, TZ_THREADS - 64, std::max(TZ_THREADS - 64, 2 * nz)));
+    p->nell = std::max(p->eg.VL, p->et.VL);
+  }
   if (klist.empty()) klist.push_back(0);
   p->nklist = std::max((int)klist.size(), (Kc + 3) / 4 + 1);     // the LDS k-list area doubles as the super-step mask table (ksplit)
   TZ_HIP(p->klist.upload(klist)); TZ_HIP(p->items.upload(items_sorted)); TZ_HIP(p->item_ptr.upload(item_ptr));
@@ -447,7 +496,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   p->chol1 = (p->Tz <= 16);
   if (const char* e = getenv("TZ_CHOL1")) { if (e[0] == '0') p->chol1 = false; }
   if (const char* e = getenv("TZ_KSPLIT")) { if (e[0] == '0') p->ksplit = false; }
-  p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist, p->ntheta, p->ksplit ? 1 : 0, p->ntube) * sizeof(double);
+  p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist, p->ntheta, p->ksplit ? 1 : 0, p->ntube, p->nell) * sizeof(double);
   if (mi > 4 * TZ_THREADS) TZ_FAIL(TZ_ERR_UNSUPPORTED, "mi=%d > %d inequality rows not supported by tz_ipm_kernel", mi, 4 * TZ_THREADS);
   if (p->lds_bytes > 160 * 1024)
     TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
