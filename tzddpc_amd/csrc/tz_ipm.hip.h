@@ -32,8 +32,6 @@ struct TzEll { int L, VL; const double* val; const unsigned short* idx; const in
 struct IpmParams {
   int B, nz, mi, nzp, mip, Tz, Kc, nquads, nklist, nP;   // nP: rows of P beyond which P is zero
   const double* P;       // nzp x nzp
-  const double* G;       // mip x nzp   (row-major, zero padded)
-  const double* Gt;      // nzp x mip   (transpose)
   const double* Gp;      // (Kc+1) x (Tz+1) x 16 patches: Gp[(kc*(Tz+1) + J)*16 + 4k + j] = G[4kc+k][4J+j]; tile Tz of every row and row Kc are zero
   const IpmItem* items;  // Gram work items, grouped per wave
   const int* item_ptr;   // TZ_NWAVES + 1
@@ -76,16 +74,32 @@ __device__ inline int tz_hidx(int r, int c) {   // LDS index of H(r, c), r >= c 
 
 enum { RED_SUM = 0, RED_MAX = 1, RED_MIN = 2 };
 
+template <int CTRL>
+__device__ inline double tz_dpp_mov(double v) {                          // 64-bit DPP move (two 32-bit halves)
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ inline double tz_readlane(double v, int lane) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int OP>
+__device__ inline double tz_op(double a, double b) { return (OP == RED_SUM) ? a + b : (OP == RED_MAX ? fmax(a, b) : fmin(a, b)); }
+
+// Reduction over the 64 lanes of a wave, result in every lane.  Cross-lane moves by DPP (quad permutes, row rotations) and four
+// v_readlane for the rows of 16 -- no ds_bpermute round trips through the LDS crossbar.  Fixed combination order.
 template <int OP>
 __device__ inline double tz_wave_reduce(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    double o = __shfl_down(v, off, 64);
-    if (OP == RED_SUM) v += o;
-    else if (OP == RED_MAX) v = fmax(v, o);
-    else v = fmin(v, o);
-  }
-  return v;
+  v = tz_op<OP>(v, tz_dpp_mov<0xB1>(v));             // quad_perm [1,0,3,2]
+  v = tz_op<OP>(v, tz_dpp_mov<0x4E>(v));             // quad_perm [2,3,0,1]
+  v = tz_op<OP>(v, tz_dpp_mov<0x124>(v));            // row_ror:4
+  v = tz_op<OP>(v, tz_dpp_mov<0x128>(v));            // row_ror:8  -> every lane holds the result of its row of 16
+  const double r0 = tz_readlane(v, 0), r1 = tz_readlane(v, 16), r2 = tz_readlane(v, 32), r3 = tz_readlane(v, 48);
+  return tz_op<OP>(tz_op<OP>(r0, r1), tz_op<OP>(r2, r3));
 }
 
 // three simultaneous block reductions (ops fixed at compile time); result broadcast to all threads.
@@ -105,29 +119,6 @@ __device__ inline void tz_block_reduce3(double& a, double& b, double& c, double*
     rc = (OP2 == RED_SUM) ? rc + vc : (OP2 == RED_MAX ? fmax(rc, vc) : fmin(rc, vc));
   }
   a = ra; b = rb; c = rc;
-}
-
-// out[k] = (G in)_r for the rows r = t + 256 k this thread owns; `in` (nz entries) in LDS.
-template <int MAXR>
-__device__ inline void tz_gemv_G(const IpmParams& p, const double* in, double (&out)[MAXR]) {
-#pragma unroll
-  for (int k = 0; k < MAXR; ++k) {
-    const int r = threadIdx.x + TZ_THREADS * k;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    if (r < p.mi) {
-      const double* g = p.Gt + r;
-      const size_t ld = (size_t)p.mip;
-      int c = 0;
-      for (; c + 7 < p.nz; c += 8) {
-        const double g0 = g[c * ld], g1 = g[(c + 1) * ld], g2 = g[(c + 2) * ld], g3 = g[(c + 3) * ld];
-        const double g4 = g[(c + 4) * ld], g5 = g[(c + 5) * ld], g6 = g[(c + 6) * ld], g7 = g[(c + 7) * ld];
-        a0 += g0 * in[c]; a1 += g1 * in[c + 1]; a2 += g2 * in[c + 2]; a3 += g3 * in[c + 3];
-        a0 += g4 * in[c + 4]; a1 += g5 * in[c + 5]; a2 += g6 * in[c + 6]; a3 += g7 * in[c + 7];
-      }
-      for (; c < p.nz; ++c) a0 += g[c * ld] * in[c];
-    }
-    out[k] = (a0 + a1) + (a2 + a3);
-  }
 }
 
 // part[w][c] = sum over the rows r = w, w+4, ... of M[r][c] in[r]  (row-major M, rows x nzp; `in` in LDS).

@@ -222,7 +222,7 @@ void drain_timing(tz_problem* p) {
 IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool warm, bool track_prev) {
   IpmParams ip{};
   ip.B = B; ip.nz = p->nz; ip.mi = p->mi; ip.nzp = p->nzp; ip.mip = p->mip; ip.Tz = p->Tz; ip.Kc = p->Kc; ip.nquads = p->nquads;
-  ip.P = p->P.p; ip.G = p->G.p; ip.Gt = p->Gt.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p; ip.smask = p->smask.p; ip.eg = p->eg.view(); ip.et = p->et.view(); ip.nell = p->nell;
+  ip.P = p->P.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p; ip.smask = p->smask.p; ip.eg = p->eg.view(); ip.et = p->et.view(); ip.nell = p->nell;
   ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
   ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
   ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac; ip.mu_tol = p->tol * p->mu_factor;
@@ -415,7 +415,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
     for (int I = pp + 1; I < Tz; ++I) p->mfma_chol += (I >> 2) - ((pp + 1) >> 2) + 1;
   p->mfma_issued += p->mfma_chol;
 
-  TZ_HIP(p->P.upload(P)); TZ_HIP(p->G.upload(G)); TZ_HIP(p->Gt.upload(Gt)); TZ_HIP(p->Gp.upload(Gp));
+  TZ_HIP(p->P.upload(P)); TZ_HIP(p->Gp.upload(Gp));
   {
     const int S = (Kc + 3) / 4;
     std::vector<int> sm((size_t)S + 1, 0);
