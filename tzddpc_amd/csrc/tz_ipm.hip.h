@@ -754,8 +754,16 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   }
   else for (int i = t; i < p.nklist; i += TZ_THREADS) kl[i] = p.klist[i];
   if (fused) {
-    const int n1 = (F0.tube.pmax + 1) * F0.tube.n * F0.tube.n;
-    for (int i = t; i < p.ntube; i += TZ_THREADS) tbl[i] = (i < n1) ? F0.tube.CKpow[i] : F0.tube.T[i - n1];
+    const int n = F0.fin.n, m = F0.fin.m, nv = F0.fin.N * m;
+    const int n1 = (F0.tube.pmax + 1) * n * n, n2 = n1 + (F0.tube.pmax > 0 ? F0.tube.pmax : 1) * (n + m) * n;
+    for (int i = t; i < n2; i += TZ_THREADS) tbl[i] = (i < n1) ? F0.tube.CKpow[i] : F0.tube.T[i - n1];
+    // constants of the recovery / plant update: [A | B | K | r1 | R2 | Phi rows of xbar[1] | Gam rows of xbar[1] | Dz(v)]
+    double* ec = tbl + n2;
+    for (int i = t; i < n * n; i += TZ_THREADS) { ec[i] = F0.plant.A[i]; ec[2 * n * m + n * n + n + i] = F0.fin.R2[i]; ec[2 * n * m + 2 * n * n + n + i] = F0.fin.Phi[(size_t)n * n + i]; }
+    for (int i = t; i < n * m; i += TZ_THREADS) { ec[n * n + i] = F0.plant.Bm[i]; ec[n * n + n * m + i] = F0.plant.K[i]; }
+    for (int i = t; i < n; i += TZ_THREADS) ec[n * n + 2 * n * m + i] = F0.fin.r1[i];
+    for (int i = t; i < n * nv; i += TZ_THREADS) ec[3 * n * n + 2 * n * m + n + i] = F0.fin.Gam[(size_t)n * nv + i];
+    for (int i = t; i < nv; i += TZ_THREADS) ec[3 * n * n + 2 * n * m + n + n * nv + i] = F0.fin.Dz[i];
   }
   if (fused && t < F0.fin.n) {                    // closed-loop state [x | xbar | e] stays in LDS for all steps of this launch
     stl[t] = F0.plant.x[(size_t)b * F0.fin.n + t];
@@ -826,9 +834,10 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     // by at least the amount the old point violates the new rows; a point that is too far outside starts cold instead
     if (src == 1) { for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + c]; TZ_ROWS(k, r) l_[k] = p.lam[(size_t)b * mi + r]; }
     tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
-    double viol = 0.0, zv1 = 0.0, zv2 = 0.0;
-    TZ_ROWS(k, r) viol = fmax(viol, gx_[k] - h_[k]);
-    tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, zv1, zv2, red);
+    double viol = 0.0;
+    TZ_ROWS(k, r) { viol = fmax(viol, gx_[k] - h_[k]); sch = fmax(sch, fabs(h_[k])); }
+    for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
+    tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red);      // also the scales of the stopping test
     if (p.warm_cold > 0.0 && viol > p.warm_cold) {
       warm = false;
       TZ_ROWS(k, r) l_[k] = 1.0;
@@ -857,15 +866,14 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
     tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
   }
-  {
+  if (!warm) {
     double rmin = 1e300;
+    scq = 0.0; sch = 0.0;
     TZ_ROWS(k, r) { rmin = fmin(rmin, h_[k] - gx_[k]); sch = fmax(sch, fabs(h_[k])); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
     tz_block_reduce3<RED_MIN, RED_MAX, RED_MAX>(rmin, scq, sch, red);
-    if (!warm) {
-      const double shift = (rmin <= 1e-8) ? fmax(0.0, 1.0 - rmin) : 0.0;
-      TZ_ROWS(k, r) s_[k] = h_[k] - gx_[k] + shift;
-    }
+    const double shift = (rmin <= 1e-8) ? fmax(0.0, 1.0 - rmin) : 0.0;
+    TZ_ROWS(k, r) s_[k] = h_[k] - gx_[k] + shift;
   }
   }
   const double sc_d = 1.0 + scq, sc_p = 1.0 + sch;
@@ -1019,9 +1027,11 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     // ---- recovery (tz_finish_kernel) and plant / error update (tz_plant_kernel) of this trajectory ----------------
     const int n = F.fin.n, m = F.fin.m, N = F.fin.N, nv = N * m;
     const double* x0 = stl + n;                         // nominal state this step started from
+    const double* ec = tbl + (F.tube.pmax + 1) * n * n + (F.tube.pmax > 0 ? F.tube.pmax : 1) * (n + m) * n;   // LDS constants, see above
+    const double *cA = ec, *cB = ec + n * n, *cK = cB + n * m, *cr1 = cK + n * m, *cR2 = cr1 + n, *cPhi = cR2 + n * n, *cGam = cPhi + n * n, *cDz = cGam + n * nv;
     __syncthreads();
     if (!px_in_part) tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
-    for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = F.fin.Dz[c] * xv[c];
+    for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = cDz[c] * xv[c];
     __syncthreads();
     double acc = 0.0, z1 = 0.0, z2 = 0.0;
     for (int c = t; c < nz; c += TZ_THREADS) acc += xv[c] * (0.5 * (px_in_part ? part[c] : tz_gemvT_get(part, nzp, c)) + qv[c]);
@@ -1029,21 +1039,27 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     if (t == 0) {
       double r = F.fin.r0;
       for (int i = 0; i < n; ++i) {
-        r += F.fin.r1[i] * x0[i];
-        for (int j = 0; j < n; ++j) r += x0[i] * F.fin.R2[i * n + j] * x0[j];
+        r += cr1[i] * x0[i];
+        for (int j = 0; j < n; ++j) r += x0[i] * cR2[i * n + j] * x0[j];
       }
       F.fin.cost[(size_t)b * F.fin.cost_stride + (size_t)step * F.cost_step] = (status == 0 || status == 1) ? acc / F.fin.cost_scale + r : INFINITY;
       if (F.plant.sticky && F.plant.sticky[b] == 0 && status != 0) F.plant.sticky[b] = status;
     }
     if (F.fin.v) for (int c = t; c < nv; c += TZ_THREADS) F.fin.v[(size_t)b * nv + c] = dxv[c];
-    const int rlo = F.fin.xbar ? 0 : n, rhi = F.fin.xbar ? (N + 1) * n : 2 * n;      // only xbar[1] feeds the next step
-    for (int r = rlo + t; r < rhi; r += TZ_THREADS) {
+    if (F.fin.xbar) {                                    // whole predicted nominal trajectory (single-step launches)
+      for (int r = t; r < (N + 1) * n; r += TZ_THREADS) {
+        double a = 0.0;
+        for (int j = 0; j < n; ++j) a += F.fin.Phi[(size_t)r * n + j] * x0[j];
+        const double* g = F.fin.Gam + (size_t)r * nv;
+        for (int c = 0; c < nv; ++c) a += g[c] * dxv[c];
+        F.fin.xbar[(size_t)b * (N + 1) * n + r] = a;
+      }
+    }
+    if (t < n) {                                         // xbar[1], the next nominal state
       double a = 0.0;
-      for (int j = 0; j < n; ++j) a += F.fin.Phi[(size_t)r * n + j] * x0[j];
-      const double* g = F.fin.Gam + (size_t)r * nv;
-      for (int c = 0; c < nv; ++c) a += g[c] * dxv[c];
-      if (F.fin.xbar) F.fin.xbar[(size_t)b * (N + 1) * n + r] = a;
-      if (r >= n && r < 2 * n) tmpz[r - n] = a;
+      for (int j = 0; j < n; ++j) a += cPhi[t * n + j] * x0[j];
+      for (int c = 0; c < nv; ++c) a += cGam[t * nv + c] * dxv[c];
+      tmpz[t] = a;
     }
     __syncthreads();
     if (t < 64) {
@@ -1051,11 +1067,11 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       double xn = 0.0, xb = 0.0;
       if (t < n) {
         xn = Q.w[(size_t)b * Q.w_stride + (size_t)step * F.w_step + t];
-        for (int j = 0; j < n; ++j) xn += Q.A[t * n + j] * stl[j];
+        for (int j = 0; j < n; ++j) xn += cA[t * n + j] * stl[j];
         for (int j = 0; j < m; ++j) {
           double u = dxv[j];
-          for (int i = 0; i < n; ++i) u += Q.K[j * n + i] * stl[2 * n + i];
-          xn += Q.Bm[t * m + j] * u;
+          for (int i = 0; i < n; ++i) u += cK[j * n + i] * stl[2 * n + i];
+          xn += cB[t * m + j] * u;
           if (t == 0 && Q.u_out) Q.u_out[(size_t)b * Q.u_stride + (size_t)step * F.u_step + j] = u;
         }
         xb = tmpz[t];

@@ -53,6 +53,13 @@ struct TubeParams {
 };
 
 #define TZ_PMAX 128        // highest supported power of M_K
+template <int CTRL>
+__device__ inline double tz_quad_xor(double v) {                       // DPP quad_perm of a double (0xB1: lane^1, 0x4E: lane^2)
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 // All nt threads of the workgroup (tid) work on trajectory b.  aL: pmax * n doubles of LDS scratch; th: ntheta doubles (LDS or
 // global).  Contains one workgroup barrier; the caller adds another before th is read by other threads.
 __device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, const double* Ttab, const double* xbar0, const double* e0, double* aL, double* th, int tid, int nt) {
@@ -65,21 +72,26 @@ __device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, c
   }
   if (tid < n) { const double x0 = xbar0[tid]; th[tid] = x0; th[n + tid] = fabs(x0); }
   __syncthreads();
-  for (int e = tid; e < p.N * hs; e += nt) {
-    const int k = e / hs, idx = e % hs, pw = p.power[k];
+  for (int e = tid; e < p.N * n; e += nt) {                      // centres c_k = C_K^power[k] e0
+    const int k = e / n, i = e - k * n;
+    const double* M = CKpow + ((size_t)p.power[k] * n + i) * n;
     double a = 0.0;
-    if (idx < n) {
-      const double* M = CKpow + ((size_t)pw * n + idx) * n;
-      for (int j = 0; j < n; ++j) a += M[j] * e0[j];
-    } else {
-      const int comp = idx - n;
-      const double* T = Ttab + ((size_t)(pw - 1) * (n + m) + comp) * n;    // walks down as l goes up
-      const double* al = aL;
-#pragma unroll 4
-      for (int l = 0; l < pw; ++l, T -= (size_t)(n + m) * n, al += n)
-        for (int j = 0; j < n; ++j) a += T[j] * al[j];
+    for (int j = 0; j < n; ++j) a += M[j] * e0[j];
+    th[2 * n + k * hs + i] = a;
+  }
+  // radii: four lanes per entry (history index l = sub, sub + 4, ...), folded with two quad permutes
+  const int sub = tid & 3;
+  for (int q = tid >> 2; q < p.N * (n + m); q += nt >> 2) {
+    const int k = q / (n + m), comp = q - k * (n + m), pw = p.power[k];
+    double a = 0.0;
+    for (int l = sub; l < pw; l += 4) {
+      const double* T = Ttab + ((size_t)(pw - 1 - l) * (n + m) + comp) * n;
+      const double* al = aL + l * n;
+      for (int j = 0; j < n; ++j) a += T[j] * al[j];
     }
-    th[2 * n + e] = a;
+    a += tz_quad_xor<0xB1>(a);
+    a += tz_quad_xor<0x4E>(a);
+    if (sub == 0) th[2 * n + k * hs + n + comp] = a;
   }
 }
 
