@@ -415,14 +415,20 @@ __device__ inline void tz_gram(const IpmParams& p, double* Hq, const double* Pq,
   else tz_form_H(p, Hq, wv, kl);
 }
 
-// sqrt(d) and 1/sqrt(d) from v_rsq_f64 + two coupled Newton steps (deterministic, ~1 ulp; no f64 divide / sqrt sequences)
+#ifndef TZ_RSQ_STEPS
+#define TZ_RSQ_STEPS 1
+#endif
+// sqrt(d) and 1/sqrt(d) from v_rsq_f64 + TZ_RSQ_STEPS coupled Newton steps and one residual correction each (deterministic; no
+// f64 divide / sqrt sequences).  One step takes the ~2^-26 seed to ~2^-51, the corrections to the last bit or two.
 __device__ inline void tz_sqrt_rsqrt(double d, double& sq, double& rs) {
   double y = __builtin_amdgcn_rsq(d);
   double g = d * y, h = 0.5 * y;
   double r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+#if TZ_RSQ_STEPS > 1
   r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+#endif
   const double e = __builtin_fma(-g, g, d);
   g = __builtin_fma(e, h, g);
   double inv = h + h;
