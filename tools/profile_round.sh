@@ -9,20 +9,20 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -o t -
 cp $(find $out/${tag}_trace -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   name=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --pmc $pass --output-format csv -d $out/${tag}_pmc_$name -o p -- python3 bench.py --no-cpu-baseline --steps 20 > $out/${tag}_pmc_$name.log 2>&1 || exit 1
+  rocprofv3 --pmc $pass --output-format csv -d $out/${tag}_pmc_$name -o p -- python3 bench.py --no-cpu-baseline > $out/${tag}_pmc_$name.log 2>&1 || exit 1
 done
 python3 - "$tag" <<'PY'
 import csv, glob, collections, json, sys
 tag = sys.argv[1]; res = {}
 for f in glob.glob(f"gpurun_out/{tag}_pmc_*/**/*counter_collection.csv", recursive=True):
-    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+    per = collections.defaultdict(lambda: collections.defaultdict(float))      # (kernel, dispatch) -> counter -> value
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
         if "tz_" not in k: continue
-        acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); n[(k, row["Counter_Name"])] += 1
-    for k in acc:
-        for c, v in acc[k].items():
-            res.setdefault(k, {})[c] = {"launches": n[(k, c)], "mean_per_launch": v / n[(k, c)]}
+        per[(k, int(row["Dispatch_Id"]))][row["Counter_Name"]] += float(row["Counter_Value"])
+    for (k, d) in sorted(per):
+        for c, v in per[(k, d)].items():
+            res.setdefault(k, {}).setdefault(c, []).append(v)       # launches in dispatch order: [warm-up launch, timed launch]
 json.dump(res, open(f"gpurun_out/{tag}_pmc.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY

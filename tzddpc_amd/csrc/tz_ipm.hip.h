@@ -72,6 +72,15 @@ __device__ inline int tz_hidx(int r, int c) {   // LDS index of H(r, c), r >= c 
   return (tz_qprefix(I) + (J >> 2)) * TZ_QSTR + TZ_QROW * (r & 3) + 4 * (J & 3) + (c & 3);
 }
 
+// threadIdx.x behind an optimisation barrier.  Every routine below derives its lane offsets from a fresh copy: otherwise the
+// compiler computes the per-lane address of every array once at kernel entry (they are loop invariant), runs out of registers,
+// spills them, and re-loads them from scratch -- a memory round trip in place of one integer add.
+__device__ inline int tz_tid() {
+  int v = threadIdx.x;
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 enum { RED_SUM = 0, RED_MAX = 1, RED_MIN = 2 };
 
 template <int CTRL>
@@ -106,7 +115,8 @@ __device__ inline double tz_wave_reduce(double v) {
 template <int OP0, int OP1, int OP2>
 __device__ inline void tz_block_reduce3(double& a, double& b, double& c, double* red) {
   a = tz_wave_reduce<OP0>(a); b = tz_wave_reduce<OP1>(b); c = tz_wave_reduce<OP2>(c);
-  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tt = tz_tid();
+  int lane = tt & 63, w = tt >> 6;
   __syncthreads();                       // protect red[] from the previous use
   if (lane == 0) { red[w] = a; red[4 + w] = b; red[8 + w] = c; }
   __syncthreads();
@@ -126,7 +136,8 @@ __device__ inline void tz_block_reduce3(double& a, double& b, double& c, double*
 // W0 / NW: the product is shared by the NW waves W0 .. W0 + NW - 1 (the others must not call); partial sums part[0 .. NW).
 template <int NCG, int W0 = 0, int NW = TZ_NWAVES>
 __device__ inline void tz_gemvT_partial(const double* M, int rows, int nzp, const double* in, double* part) {
-  const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) - W0;
+  const int tt = tz_tid();
+  const int lane = tt & 63, w = (tt >> 6) - W0;
   constexpr int UR = (NCG <= 2) ? 8 : 4;
   double acc[NCG];
 #pragma unroll
@@ -165,7 +176,7 @@ __device__ inline double tz_gemvT_get3(const double* part, int nzp, int c) {
 // out[k] = (G in)_r for the rows r = t + 256 k this thread owns; `in` (nz entries) and pl (eg.VL doubles) in LDS.
 template <int MAXR>
 __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double* pl, const int (&rseg)[MAXR], double (&out)[MAXR]) {
-  const int t = threadIdx.x, L = p.eg.L;
+  const int t = tz_tid(), L = p.eg.L;
   __syncthreads();                                   // pl may still be read by the owners of the previous product
   for (int v0 = 0; v0 < p.eg.VL; v0 += TZ_THREADS) {
     const double* val = p.eg.val + (size_t)v0 * L + t;
@@ -194,7 +205,7 @@ __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double*
 // LDS.  After the next workgroup barrier tz_ell_colsum(pl, cseg) is column c's value for the thread holding cseg = et.seg[c].
 __device__ inline void tz_ell_gemvT_part(const IpmParams& p, const double* in, double* pl) {
   constexpr int NL = TZ_THREADS - 64;
-  const int l = threadIdx.x - 64, L = p.et.L;
+  const int l = tz_tid() - 64, L = p.et.L;
   for (int v0 = 0; v0 < p.et.VL; v0 += NL) {
     const double* val = p.et.val + (size_t)v0 * L + l;
     const unsigned short* idx = p.et.idx + (size_t)v0 * L + l;
@@ -327,7 +338,7 @@ __device__ inline double tz_row_ror(double v) {                          // valu
 template <int R0, int R1>
 __device__ inline void tz_gram_rows(const IpmParams& p, double* Hq, const double* Pq, const double* wv, const int* sm, const int h, unsigned long long* pacc) {
   unsigned long long tq0 = pacc ? __builtin_amdgcn_s_memtime() : 0;
-  const int lane = threadIdx.x & 63;
+  const int lane = tz_tid() & 63;
   const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
   const int Tz = p.Tz, Kc = p.Kc, S = (Kc + 3) >> 2;
   const unsigned rowbytes = (unsigned)(Tz + 1) * 128u;
@@ -563,7 +574,7 @@ __device__ inline void tz_wave_sync() {
 }
 __device__ inline void tz_cholesky_wave(const IpmParams& p, double* Hq, double* dinv, int* flag) {
   const int Tz = p.Tz;
-  const int lane = threadIdx.x & 63;
+  const int lane = tz_tid() & 63;
   const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
   for (int pp = 0; pp < Tz; ++pp) {
     if (pp > 0) {
@@ -612,7 +623,7 @@ __device__ inline void tz_cholesky_wave(const IpmParams& p, double* Hq, double* 
 __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const double* dinv,
                                      const double* rhs, double* ybuf, double* out) {
   const int Tz = p.Tz, nzp = p.nzp;
-  const int t = threadIdx.x, jq = t & 3, tq = t >> 2, wave = t >> 6;
+  const int t = tz_tid(), jq = t & 3, tq = t >> 2, wave = t >> 6;
   const int nblk = (Tz + 15) >> 4;
   double rv = (t < nzp) ? rhs[t] : 0.0;
   const int rowbase = tz_qprefix(tq) * TZ_QSTR + TZ_QROW * jq;                    // + (I>>2)*64 + 4(I&3): L(t, 4I + .)
@@ -706,7 +717,8 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   if (PROF) { tprev = __builtin_amdgcn_s_memtime(); tstart = tprev; }
   extern __shared__ double lds[];
   const int b = blockIdx.x;
-  const int t = threadIdx.x;
+  int t = threadIdx.x;                     // re-laundered at phase boundaries (TZ_FRESH_T, see tz_tid)
+#define TZ_FRESH_T() asm volatile("" : "+v"(t))
   const bool wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
   const int nz = p.nz, mi = p.mi, nzp = p.nzp, mip = p.mip;
   const FuseParams& F0 = p.F;
@@ -787,6 +799,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   for (int step = 0; step < nsteps; ++step) {     // closed-loop steps of this trajectory (one when the launch is a single solve)
   // start point of this step: 0 cold, 1 the (x, lambda) stored by an earlier launch, 2 the (x, lambda) of the previous step (still
   // in LDS / registers)
+  TZ_FRESH_T();
   int src = 0;
   if (step == 0) src = (p.warm != 0 && p.prev_status != nullptr && p.prev_status[b] == 0) ? 1 : 0;
   else src = (p.warm_steps != 0 && status == 0) ? 2 : 0;
@@ -887,6 +900,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   status = skip ? 3 : (okf ? 1 : 2);
   bool px_in_part = false;                  // `part` holds the partial sums of P x for the final x (left there by exact_rd)
   for (it = 0; it < p.max_iter && status == 1; ++it) {
+    TZ_FRESH_T();
     TZ_STAMP(PH_ELEM);
     // primal residual rp = G x + s - h and complementarity every iteration; the dual residual rd = P x + q + G'lambda is not
     // carried along at all: the right-hand sides below are written without it, and it is evaluated (exactly) only when rp and
@@ -915,6 +929,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     tz_gram(p, Hq, Pq, vin, kl, (PROF && t == 0) ? acc_ph : nullptr);
     __syncthreads();
     TZ_STAMP(PH_FORM);
+    TZ_FRESH_T();
     // ---- predictor (rc = s*lam):  H dx = -(P x + q) - G'(w rp).  The factorisation of H and the two products on the right
     // are independent: with chol1 wave 0 factors while waves 1-3 form the right-hand side.
     TZ_ROWS(k, r) vin[r] = w_[k] * rp_[k];
@@ -950,12 +965,14 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       TZ_STAMP(PH_CHOL);
     }
     if (!okc) { status = 2; break; }
+    TZ_FRESH_T();
     tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
     tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
     TZ_STAMP(PH_GEMV);
     // step to the boundary: alpha = 1 / max(1, max_i(-dv_i / v_i))
+    TZ_FRESH_T();
     double mp = 0.0, md = 0.0, z4 = 0;
     TZ_ROWS(k, r) {
       const double ds = -rp_[k] - g_[k];
@@ -981,6 +998,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       continue;
     }
     double sigma = muaff / mu; sigma = sigma * sigma * sigma;
+    TZ_FRESH_T();
     // ---- corrector (rc = s*lam + dsa*dla - sigma mu):  H dx = -(P x + q) - G'(lam + (lam rp - rc) / s) -------------------
     TZ_ROWS(k, r) {
       const double rc = s_[k] * l_[k] + ds_[k] * dl_[k] - sigma * mu;
@@ -1015,6 +1033,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     TZ_ROWS(k, r) { s_[k] += alpha * ds_[k]; l_[k] += alpha * dl_[k]; gx_[k] += alpha * g_[k]; }
     __syncthreads();
   }
+  TZ_FRESH_T();
   work_f += (unsigned long long)(it + ((warm || skip) ? 0 : 1)); work_s += 1;
   if (step == nsteps - 1) {                 // what a later launch (or the host) reads: solution, multipliers, status
     for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = xv[c];
@@ -1101,4 +1120,5 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   }
 #undef TZ_STAMP
 #undef TZ_ROWS
+#undef TZ_FRESH_T
 }
