@@ -750,7 +750,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   double* Pq = tbl + p.ntube;                       // ksplit: P + reg I in the quad layout of Hq (lower tiles)
 
   // rows owned by this thread
-  double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR], w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR], is_[MAXR], il_[MAXR];
+  double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR];        // live across iterations (s, lambda also across steps)
 #define TZ_ROWS(k, r) _Pragma("unroll") for (int k = 0; k < MAXR; ++k) if (const int r = t + TZ_THREADS * k; r < mi)
   int rseg_[MAXR];                                   // lanes of the G x product that carry this thread's rows
 #pragma unroll
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     stl[2 * F0.fin.n + t] = F0.plant.e[(size_t)b * F0.fin.n + t];
   }
 #pragma unroll
-  for (int k = 0; k < MAXR; ++k) { s_[k] = 1.0; l_[k] = 0.0; h_[k] = 0.0; gx_[k] = 0.0; w_[k] = 0.0; rp_[k] = 0.0; ds_[k] = 0.0; dl_[k] = 0.0; g_[k] = 0.0; is_[k] = 1.0; il_[k] = 1.0; }
+  for (int k = 0; k < MAXR; ++k) { s_[k] = 1.0; l_[k] = 0.0; h_[k] = 0.0; gx_[k] = 0.0; }
   for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
   __syncthreads();
 
@@ -902,6 +902,9 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   for (it = 0; it < p.max_iter && status == 1; ++it) {
     TZ_FRESH_T();
     TZ_STAMP(PH_ELEM);
+    double w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR], is_[MAXR], il_[MAXR];      // scratch of this iteration only
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) { w_[k] = 0.0; rp_[k] = 0.0; ds_[k] = 0.0; dl_[k] = 0.0; g_[k] = 0.0; is_[k] = 1.0; il_[k] = 1.0; }
     // primal residual rp = G x + s - h and complementarity every iteration; the dual residual rd = P x + q + G'lambda is not
     // carried along at all: the right-hand sides below are written without it, and it is evaluated (exactly) only when rp and
     // mu already pass the test
