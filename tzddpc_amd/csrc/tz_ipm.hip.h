@@ -809,6 +809,9 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   TzKargPtr kp0 = (TzKargPtr)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(kp0));
   const FuseParams& F = ((const IpmParams*)kp0)->F;
+  // this step's disturbance is needed only by the plant update at the very end: fetch it now, the round trip hides behind the solve
+  double w_now = 0.0;
+  if (fused && t < F.fin.n) w_now = F.plant.w[(size_t)b * F.plant.w_stride + (size_t)step * F.w_step + t];
   bool skip = false;                        // fused step: a parameter row is violated -> status 3, u = K e, nominal state from Phi
   for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the cold start point
   if (fused) {
@@ -1094,7 +1097,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
       const PlantParams& Q = F.plant;
       double xn = 0.0, xb = 0.0;
       if (t < n) {
-        xn = Q.w[(size_t)b * Q.w_stride + (size_t)step * F.w_step + t];
+        xn = w_now;
         for (int j = 0; j < n; ++j) xn += cA[t * n + j] * stl[j];
         for (int j = 0; j < m; ++j) {
           double u = dxv[j];
