@@ -179,6 +179,13 @@ def main():
                                  "count is given beside it; prologue / recovery / plant work of the fused step is not counted"},
         }
         line["config"]["gathered_rows"] = int(gathered.shape[0])
+        try:      # HBM-side bytes of the timed launch as measured by the PMC passes committed under profiles/ (same steps and batch only)
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            if tr["steps"] == K and tr["trajectories_per_gpu"] == Bl and ipm_n == 1:
+                line["roofline"]["traffic"] = tr["fetch_bytes"] + tr["write_bytes"]
+                line["roofline"]["traffic_source"] = tr["source"]
+        except Exception:
+            pass
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(ctl, A, Bm, zon, args.horizon, W, K)
