@@ -273,6 +273,12 @@ static void solve_one(const tzo_desc* d, const setup_t* S, const double* xbar0, 
       h[k] = S->E[k] * S->sgn[k] * a;
     }
     st = ipm(d, S, q, h, x, s, lam, &it, iw, warm);
+    if (st != 0) {                      /* same safeguard as the device kernel: once more, cold, textbook fraction to the boundary */
+      tzo_desc d2 = *d; int it2 = 0;
+      d2.step_frac = fmin(d->step_frac, 0.99);
+      st = ipm(&d2, S, q, h, x, s, lam, &it2, iw, 0);
+      it += it2;
+    }
   } else { for (int c = 0; c < nz; ++c) x[c] = 0; }
   *status = st; if (iters) *iters = it;
   double obj = 0;

@@ -847,6 +847,11 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     __syncthreads();
   };
 
+  // A solve that does not end in TZ_SOLVED (in practice: the aggressive fraction to the boundary collapsing mu before the
+  // residuals on a degenerate problem, ~2e-5 of the pulley steps) is repeated once from a cold start with the textbook 0.99.
+  int attempt = 0;
+  double sfrac = p.step_frac;
+retry_solve:
   bool okf = true;
   bool warm = !skip && src != 0;     // the previous step of this trajectory was solved: start from it
   double scq = 0, sch = 0;
@@ -993,7 +998,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     TZ_ROWS(k, r) muaff += (s_[k] + ap * ds_[k]) * (l_[k] + ad * dl_[k]);
     tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(muaff, z1, z2, red);
     muaff /= mi;
-    const double sfr = (p.sf_gain > 0.0) ? fmin(p.sf_cap, fmax(p.step_frac, 1.0 - p.sf_gain * mu)) : p.step_frac;
+    const double sfr = (p.sf_gain > 0.0) ? fmin(p.sf_cap, fmax(sfrac, 1.0 - p.sf_gain * mu)) : sfrac;
     if (fmin(ap, ad) >= p.aff_thr && muaff <= p.aff_mu * mu) {
       // the Newton (predictor) step is already (almost) a full step and kills complementarity: take it, skip the corrector
       const double mmA = fmax(mp, md);
@@ -1040,7 +1045,18 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
     __syncthreads();
   }
   TZ_FRESH_T();
-  work_f += (unsigned long long)(it + ((warm || skip) ? 0 : 1)); work_s += 1;
+  work_f += (unsigned long long)(it + ((warm || skip) ? 0 : 1));
+  if (status != 0 && !skip && attempt == 0) {
+    attempt = 1; src = 0; sfrac = fmin(sfrac, 0.99);
+    __syncthreads();
+    if (t == 0) flag[0] = 0;
+    for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
+    for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;
+    TZ_ROWS(k, r) { s_[k] = 1.0; l_[k] = 1.0; }
+    __syncthreads();
+    goto retry_solve;
+  }
+  work_s += 1;
   if (step == nsteps - 1) {                 // what a later launch (or the host) reads: solution, multipliers, status
     for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = xv[c];
     TZ_ROWS(k, r) { p.s[(size_t)b * mi + r] = s_[k]; p.lam[(size_t)b * mi + r] = l_[k]; }
