@@ -161,8 +161,9 @@ int tz_simulate_batch(tz_problem* p, int32_t B, int32_t T, const double* x0, con
 int tz_mpc_step(tz_problem* p, int32_t B, double* x, double* xbar, double* e, const double* w,
                 const double* A_true, const double* B_true, double* u_out, double* cost, int32_t* status);
 
-/* K consecutive tz_mpc_step calls issued from one C loop (no host work between steps): w holds the noise of the K steps,
- * step-major (K x B x n); u_out / cost keep the values of the last step; status is the sticky first non-zero status. */
+/* K consecutive closed-loop steps of every trajectory in ONE kernel launch (each workgroup loops over the steps of its
+ * trajectory; state and warm start stay on chip): w holds the noise of the K steps, step-major (K x B x n); u_out / cost keep
+ * the values of the last step; status is the sticky first non-zero status.  Same results as K calls of tz_mpc_step. */
 int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, double* e, const double* w,
                const double* A_true, const double* B_true, double* u_out, double* cost, int32_t* status);
 
@@ -182,7 +183,8 @@ int tz_ipm_plan_info(tz_problem* p, int64_t* mfma_gram_per_iter, int64_t* mfma_c
                      int64_t* mfma_issued_per_iter, int64_t* lds_bytes, int64_t* patch_bytes);
 
 /* Test hook: copy device-side intermediates of trajectory `b` of the last solve to the host.
- * what: 0 = theta (ntheta), 1 = q (nz), 2 = h (mi), 3 = x (nz), 4 = s (mi), 5 = lambda (mi) */
+ * what: 0 = theta (ntheta), 1 = q (nz), 2 = h (mi)  [0-2: only after tz_solve_batch, the closed-loop launches keep them on chip],
+ *       3 = x (nz), 4 = s (mi), 5 = lambda (mi), 6 = per-phase cycle sums (diagnostic build), 7 = iterations of every trajectory */
 int tz_debug_fetch(tz_problem* p, int32_t b, int what, double* out, int32_t capacity);
 
 #ifdef __cplusplus
