@@ -1076,14 +1076,18 @@ retry_solve:
     const double* x0 = stl + n;                         // nominal state this step started from
     const double* ec = tbl + (F.tube.pmax + 1) * n * n + (F.tube.pmax > 0 ? F.tube.pmax : 1) * (n + m) * n;   // LDS constants, see above
     const double *cA = ec, *cB = ec + n * n, *cK = cB + n * m, *cr1 = cK + n * m, *cR2 = cr1 + n, *cPhi = cR2 + n * n, *cGam = cPhi + n * n, *cDz = cGam + n * nv;
+    const bool want_cost = F.cost_step != 0 || step == nsteps - 1;      // a cost that the next step overwrites is not formed
     __syncthreads();
-    if (!px_in_part) tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
+    if (want_cost && !px_in_part) tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
     for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = cDz[c] * xv[c];
     __syncthreads();
     double acc = 0.0, z1 = 0.0, z2 = 0.0;
-    for (int c = t; c < nz; c += TZ_THREADS) acc += xv[c] * (0.5 * (px_in_part ? part[c] : tz_gemvT_get(part, nzp, c)) + qv[c]);
-    tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(acc, z1, z2, red);
-    if (t == 0) {
+    if (want_cost) {
+      for (int c = t; c < nz; c += TZ_THREADS) acc += xv[c] * (0.5 * (px_in_part ? part[c] : tz_gemvT_get(part, nzp, c)) + qv[c]);
+      tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(acc, z1, z2, red);
+    }
+    if (t == 0 && !want_cost) { if (F.plant.sticky && F.plant.sticky[b] == 0 && status != 0) F.plant.sticky[b] = status; }
+    if (t == 0 && want_cost) {
       double r = F.fin.r0;
       for (int i = 0; i < n; ++i) {
         r += cr1[i] * x0[i];
