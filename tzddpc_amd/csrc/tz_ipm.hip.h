@@ -697,6 +697,59 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
   if (t < nzp) out[t] = rv;
 }
 
+// (L L') out = rhs for matrices of at most 16 tile columns (nzp <= 64): wave 0 alone, lane = row, the value of every unknown
+// travels by v_readlane instead of an LDS publish + wave sync + read -- per tile step the dependent chain is four DPP quad
+// broadcasts, the 4x4 inverse-diagonal product, four readlanes and one fused update; the L / M entries of the next step are
+// independent LDS reads.  Called by all threads (waves 1-3 fall through); the caller's barrier publishes out.
+__device__ inline void tz_chol_solve_wave(const IpmParams& p, const double* Hq, const double* dinv, const double* rhs, double* out) {
+  const int tt = tz_tid();
+  if (tt >= 64) return;
+  const int Tz = p.Tz, nzp = p.nzp;
+  const int t = tt, jq = t & 3, tq = t >> 2;
+  double rv = (t < nzp) ? rhs[t] : 0.0;
+  const int rowbase = tz_qprefix(tq < Tz ? tq : 0) * TZ_QSTR + TZ_QROW * jq;       // + (I>>2)*QSTR + 4(I&3): L(t, 4I + .)
+  // operands of tile step I are independent of the running solution: those of the next step are fetched while this one computes
+  auto fwd_load = [&](int I, double (&mm)[4], double (&ll)[4]) {
+    const int Ic = I < Tz ? I : Tz - 1;
+    const double* m = dinv + Ic * 16 + 4 * jq;                         // row jq of M_I = inv(L_II)
+    const int base = rowbase + (Ic >> 2) * TZ_QSTR + 4 * (Ic & 3);
+    const bool below = tq > Ic && tq < Tz;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mm[k] = m[k]; ll[k] = below ? Hq[base + k] : 0.0; }
+  };
+  double mA[4], lA[4], mB[4], lB[4];
+  auto fwd_step = [&](int I, const double (&mm)[4], const double (&ll)[4]) {
+    const double a0 = tz_quad_bcast<0>(rv), a1 = tz_quad_bcast<1>(rv), a2 = tz_quad_bcast<2>(rv), a3 = tz_quad_bcast<3>(rv);
+    const double yc = (mm[0] * a0 + mm[1] * a1) + (mm[2] * a2 + mm[3] * a3);       // y of this quad if it is the owner (tq == I)
+    const double y0 = tz_readlane(yc, 4 * I), y1 = tz_readlane(yc, 4 * I + 1), y2 = tz_readlane(yc, 4 * I + 2), y3 = tz_readlane(yc, 4 * I + 3);
+    rv = (tq == I) ? yc : rv - ((ll[0] * y0 + ll[1] * y1) + (ll[2] * y2 + ll[3] * y3));
+  };
+  fwd_load(0, mA, lA);
+  for (int I = 0; I < Tz; I += 2) {                                    // ---- forward: L y = rhs
+    fwd_load(I + 1, mB, lB);
+    fwd_step(I, mA, lA);
+    fwd_load(I + 2, mA, lA);
+    if (I + 1 < Tz) fwd_step(I + 1, mB, lB);
+  }
+  const int colbase = (t >> 4) * TZ_QSTR + 4 * ((t >> 2) & 3) + (t & 3);        // + qprefix(I)*QSTR + QROW k: L(4I + k, t)
+  auto bwd_load = [&](int I, double (&mm)[4], double (&ll)[4]) {
+    const int Ic = I >= 0 ? I : 0;
+    const double* m = dinv + Ic * 16 + jq;                             // column jq of M_I
+    const int base = tz_qprefix(Ic) * TZ_QSTR + colbase;
+    const bool above = tq < Ic;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mm[k] = m[4 * k]; ll[k] = above ? Hq[base + k * TZ_QROW] : 0.0; }
+  };
+  bwd_load(Tz - 1, mA, lA);
+  for (int I = Tz - 1; I >= 0; I -= 2) {                               // ---- backward: L' x = y
+    bwd_load(I - 1, mB, lB);
+    fwd_step(I, mA, lA);                                               // same arithmetic with the transposed operands
+    bwd_load(I - 2, mA, lA);
+    if (I - 1 >= 0) fwd_step(I - 1, mB, lB);
+  }
+  if (t < nzp) out[t] = rv;
+}
+
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
 __host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit, int ntube, int nell) {
   return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 14 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX + (size_t)ntube + (size_t)nell;
@@ -890,7 +943,7 @@ retry_solve:
     __syncthreads();
     if (p.chol1) { if (wave0) tz_cholesky_wave(p, Hq, dinv, flag); __syncthreads(); okf = (*flag == 0); }
     else okf = tz_cholesky(p, Hq, dinv, flag);
-    tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
+    if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, xv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
     tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
   }
   if (!warm) {
@@ -977,7 +1030,7 @@ retry_solve:
     }
     if (!okc) { status = 2; break; }
     TZ_FRESH_T();
-    tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
+    if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, dxv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
     tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
@@ -1023,7 +1076,7 @@ retry_solve:
     for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? -rdv[c] - tz_ell_colsum(pl, cseg) : 0.0;
     __syncthreads();
     TZ_STAMP(PH_GEMVT);
-    tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
+    if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, dxv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
     tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
