@@ -52,10 +52,9 @@ struct IpmParams {
   int chol1;                  // Tz <= 16: one wave factors H while the other three form the predictor's right-hand side
   int ksplit;                 // Gram by tz_form_H_ksplit (Tz <= TZ_KS_TZ) instead of the item plan
   int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
-  double warm_gain, warm_cold;   // warm point pushed into the cone by max(warm_floor, warm_gain * violation); violation > warm_cold: cold start
+  double warm_gain;              // warm point pushed into the cone by max(warm_floor, warm_gain * violation of the new rows)
   double aff_thr, aff_mu;        // predictor step taken as the step (no corrector solve) when it reaches aff_thr of the way to the
                                  // boundary un-damped and leaves mu_aff <= aff_mu * mu; aff_thr > 1 disables
-  double sf_gain, sf_cap;        // fraction to the boundary = min(sf_cap, max(step_frac, 1 - sf_gain * mu))
   unsigned long long* work;   // [0] += factorisations, [1] += solved trajectories (bench.py roofline accounting); may be null
   unsigned long long* prof;   // TZ_PROF=1: per-phase cycle sums of workgroup 0 (diagnostic; no output depends on it)
   FuseParams F;               // F.on != 0: whole closed-loop step in this launch (q, h, prestatus above are then unused)
@@ -918,17 +917,10 @@ retry_solve:
     TZ_ROWS(k, r) { viol = fmax(viol, gx_[k] - h_[k]); sch = fmax(sch, fabs(h_[k])); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
     tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red);      // also the scales of the stopping test
-    if (p.warm_cold > 0.0 && viol > p.warm_cold) {
-      warm = false;
-      TZ_ROWS(k, r) l_[k] = 1.0;
-      for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
-      __syncthreads();
-    } else {
-      const double sig = fmax(p.warm_floor, p.warm_gain * viol);
-      TZ_ROWS(k, r) {
-        s_[k] = fmax(h_[k] - gx_[k], sig);
-        l_[k] = fmax(l_[k], sig);
-      }
+    const double sig = fmax(p.warm_floor, p.warm_gain * viol);
+    TZ_ROWS(k, r) {
+      s_[k] = fmax(h_[k] - gx_[k], sig);
+      l_[k] = fmax(l_[k], sig);
     }
   }
   if (!warm) {
@@ -1051,7 +1043,7 @@ retry_solve:
     TZ_ROWS(k, r) muaff += (s_[k] + ap * ds_[k]) * (l_[k] + ad * dl_[k]);
     tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(muaff, z1, z2, red);
     muaff /= mi;
-    const double sfr = (p.sf_gain > 0.0) ? fmin(p.sf_cap, fmax(sfrac, 1.0 - p.sf_gain * mu)) : sfrac;
+    const double sfr = sfrac;
     if (fmin(ap, ad) >= p.aff_thr && muaff <= p.aff_mu * mu) {
       // the Newton (predictor) step is already (almost) a full step and kills complementarity: take it, skip the corrector
       const double mmA = fmax(mp, md);

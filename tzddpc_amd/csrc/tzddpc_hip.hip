@@ -143,7 +143,7 @@ struct tz_problem {
   int lastB = 0;
   bool prof = false;
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
-  double warm_floor = 1e-8, warm_gain = 1.0, warm_cold = 0.0, sf_gain = 0.0, sf_cap = 1.0, mu_factor = 0.1, aff_thr = 0.99, aff_mu = 1e-3;
+  double warm_floor = 1e-8, warm_gain = 1.0, mu_factor = 0.1, aff_thr = 0.99, aff_mu = 1e-3;
   bool warm_enabled = true;
   int ntube = 0;
   bool chol1 = false;          // single-wave Cholesky overlapped with the predictor's G' product (Tz <= 16; TZ_CHOL1=0 disables)
@@ -230,7 +230,7 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.work = p->timing ? p->work_buf.p : nullptr;
   ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0; ip.chol1 = p->chol1 ? 1 : 0; ip.ntube = p->ntube;
   ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
-  ip.warm_gain = p->warm_gain; ip.warm_cold = p->warm_cold; ip.sf_gain = p->sf_gain; ip.sf_cap = p->sf_cap; ip.aff_thr = p->aff_thr; ip.aff_mu = p->aff_mu;
+  ip.warm_gain = p->warm_gain; ip.aff_thr = p->aff_thr; ip.aff_mu = p->aff_mu;
   ip.prev_status = warm ? p->prev_status.p : nullptr;
   ip.status_copy = track_prev ? p->prev_status.p : nullptr;
   ip.F.on = 0;
@@ -511,9 +511,6 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if ((size_t)p->pmax * p->n > (size_t)p->nquads * TZ_QSTR) p->fuse_enabled = false;   // tube scratch borrows the factor storage
   if (const char* e = getenv("TZ_WARM_FLOOR")) { double v = atof(e); if (v > 0) p->warm_floor = v; }
   if (const char* e = getenv("TZ_WARM_GAIN")) p->warm_gain = atof(e);
-  if (const char* e = getenv("TZ_WARM_COLD")) p->warm_cold = atof(e);
-  if (const char* e = getenv("TZ_SF_GAIN")) p->sf_gain = atof(e);
-  if (const char* e = getenv("TZ_SF_CAP")) p->sf_cap = atof(e);
   if (const char* e = getenv("TZ_MU_FACTOR")) p->mu_factor = atof(e);
   if (const char* e = getenv("TZ_AFF_THR")) p->aff_thr = atof(e);
   if (const char* e = getenv("TZ_AFF_MU")) p->aff_mu = atof(e);
