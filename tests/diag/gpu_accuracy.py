@@ -1,5 +1,5 @@
 """Closed-loop accuracy of the device path against a tight cold-started solve of the C oracle (same inputs).
-   python tools/gpu_accuracy.py [case] ; solver knobs through TZ_* environment variables."""
+   python tests/diag/gpu_accuracy.py [case] ; solver knobs through TZ_* environment variables."""
 import os, sys, numpy as np
 sys.path.insert(0, ".")
 from tests import common
