@@ -39,6 +39,8 @@ CASES = {
     "di_n5": ("di_cc", loss_di, nocons, 5, None),
     "di_n20": ("di_cc", loss_di, nocons, 20, None),
     "di_n20_k1": ("di_cc", loss_di, nocons, 20, 1),
+    "di_n10": ("di_cc", loss_di, nocons, 10, None),
+    "di_n40": ("di_cc", loss_di, nocons, 40, None),
     "pulley_n10": ("pulley", loss_pulley, nocons, 10, None),
     "dim5_n20": ("dim5_w001", loss_dim5, cons_dim5, 20, None),
 }

@@ -212,6 +212,24 @@ def test_large_closed_loop_batches_all_solved(built):
         assert np.all(out["x"] >= Xi.left_limit - 1e-9) and np.all(out["x"] <= Xi.right_limit + 1e-9)
 
 
+@pytest.mark.parametrize("case", ["di_n5", "di_n10", "di_n20", "di_n40"])
+def test_horizon_sweep_against_c_oracle(built, case):
+    """BASELINE config 5 (complexity-scaling reproduction): the same closed loop at N = 5 .. 40 on the device and in the plain-C
+    oracle (N = 80 does not fit the on-chip factor and is refused at build time, see test_unsupported_sizes_fail_loudly)."""
+    from oracle.c_oracle import COracle
+    from tzddpc_amd.dist import vertex_noise
+    ctl, (A, B, zon) = common.gpu_controller(case)
+    Bn, T = 48, 10
+    noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
+    x0 = np.tile(zon.X0.center, (Bn, 1))
+    dev = ctl.simulate_batch(x0, noise, A, B)
+    ref = COracle(ctl.qp).simulate_batch(x0, noise, A, B, threads=16)
+    assert (dev["status"] == 0).all() and (ref["status"] == 0).all()
+    np.testing.assert_allclose(dev["x"], ref["x"], atol=1e-6)
+    np.testing.assert_allclose(dev["u"], ref["u"], atol=1e-6)
+    np.testing.assert_allclose(dev["cost"], ref["cost"], rtol=1e-7, atol=1e-7)
+
+
 def test_reference_example_loop_runs_unchanged(built):
     """examples/di_closed_loop.py = reference examples/1.double_integrator_sim.py:20-95 with only the imports changed."""
     import importlib.util
