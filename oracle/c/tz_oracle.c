@@ -176,13 +176,17 @@ static double max_step(int n, const double* v, const double* dv) {
 /* warm != 0: x / lam hold the previous closed-loop step's solution of this trajectory; the slacks are re-derived for the
  * new h and (s, lam) pushed into the cone by max(warm_floor, warm_gain * largest violation of the new rows). */
 static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const double* h, double* x, double* s, double* lam, int* iters, double* wk, int warm) {
+  /* warm == 2: as warm == 1 and gx (G x of the starting point) is still valid in the work area from the previous step */
   int nz = S->nz, mi = S->mi;
   double* H = wk; double* GW = H + nz * nz;
   double* w = GW + mi * nz; double* rd = w + mi; double* rp = rd + nz; double* r1 = rp + mi;
   double* dx = r1 + nz; double* ds = dx + nz; double* dl = ds + mi; double* t1 = dl + mi; double* gx = t1 + mi; double* gdx = gx + mi; double* rc = gdx + mi;
   if (warm) {
     double viol = 0;
-    for (int r = 0; r < mi; ++r) { double a = 0; for (int c = 0; c < nz; ++c) a += S->G[r * nz + c] * x[c]; gx[r] = a; viol = fmax(viol, a - h[r]); }
+    for (int r = 0; r < mi; ++r) {
+      if (warm != 2) { double a = 0; for (int c = 0; c < nz; ++c) a += S->G[r * nz + c] * x[c]; gx[r] = a; }
+      viol = fmax(viol, gx[r] - h[r]);
+    }
     double sig = fmax(d->warm_floor, d->warm_gain * viol);
     for (int r = 0; r < mi; ++r) { s[r] = fmax(h[r] - gx[r], sig); lam[r] = fmax(lam[r], sig); }
   } else {
@@ -344,7 +348,7 @@ int tzo_simulate_batch(const tzo_desc* d, int B, int T, const double* x0, const 
       for (int i = 0; i < n; ++i) { x[i] = x0[(size_t)b * n + i]; xbar[i] = x[i]; e[i] = 0; x_traj[((size_t)b * (T + 1)) * n + i] = x[i]; }
       for (int t = 0; t < T; ++t) {
         int32_t st, it; double c;
-        solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk, prev_ok);   /* x / s / lam of the previous step live on in wk */
+        solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk, prev_ok ? ((t & 7) ? 2 : 1) : 0);   /* x / s / lam (and G x) of the previous step live on in wk */
         prev_ok = (st == 0) && d->warm_floor > 0;
         if (!sticky && st) sticky = st;
         if (cost) cost[(size_t)b * T + t] = c;

@@ -904,6 +904,7 @@ __global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmPara
   int attempt = 0;
   double sfrac = p.step_frac;
 retry_solve:
+  const bool retried = attempt != 0;
   bool okf = true;
   bool warm = !skip && src != 0;     // the previous step of this trajectory was solved: start from it
   double scq = 0, sch = 0;
@@ -912,7 +913,9 @@ retry_solve:
     // ---- warm start: previous (x, lambda) of this trajectory, slacks re-derived for the new h and pushed into the cone
     // by at least the amount the old point violates the new rows; a point that is too far outside starts cold instead
     if (src == 1) { for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + c]; TZ_ROWS(k, r) l_[k] = p.lam[(size_t)b * mi + r]; }
-    tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
+    // G x of the starting point: inside a launch gx_ still holds it (it followed x through the iterations of the previous
+    // step); it is formed afresh every eighth step so that rounding does not accumulate along a trajectory
+    if (src != 2 || (step & 7) == 0 || retried) tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
     double viol = 0.0;
     TZ_ROWS(k, r) { viol = fmax(viol, gx_[k] - h_[k]); sch = fmax(sch, fabs(h_[k])); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
