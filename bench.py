@@ -73,6 +73,23 @@ def cpu_baseline(ctl, A, B, zon, horizon, warmup, steps, seconds_budget=40.0):
                       f"all statuses zero: {bool((out['status'] == 0).all())}"}
 
 
+def ensure_built():
+    """The in-tree libraries normally travel with the snapshot; on a bare checkout build them once (one rank at a time)."""
+    import fcntl
+    lib = os.path.join(ROOT, "tzddpc_amd", "lib", "libtzddpc_hip.so")
+    orc = os.path.join(ROOT, "oracle", "_build", "libtz_oracle.so")
+    if os.path.exists(lib) and os.path.exists(orc):
+        return
+    os.makedirs(os.path.join(ROOT, "tzddpc_amd", "lib"), exist_ok=True)
+    with open(os.path.join(ROOT, "tzddpc_amd", "lib", ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            import __graft_entry__
+            __graft_entry__.build()
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +100,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    ensure_built()
     import torch
     import torch.distributed as dist
     from tzddpc_amd.dist import gather_results, shard_range, vertex_noise
