@@ -50,8 +50,8 @@ struct DevEll {
   int L = 1, VL = 0;
   hipError_t build(const std::vector<std::vector<std::pair<int, double>>>& outs, int NL, int VLwant) {
     VL = ((std::max(VLwant, 1) + NL - 1) / NL) * NL;
-    size_t nnz = 0; size_t longest = 1;
-    for (auto& o : outs) { nnz += o.size(); longest = std::max(longest, o.size()); }
+    size_t longest = 1;
+    for (auto& o : outs) longest = std::max(longest, o.size());
     for (L = 1; L <= (int)longest; ++L) {
       size_t lanes = 0;
       for (auto& o : outs) lanes += (o.size() + L - 1) / L;
