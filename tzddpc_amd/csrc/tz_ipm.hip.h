@@ -756,8 +756,10 @@ __host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp
 
 typedef __attribute__((address_space(4))) const IpmParams* TzKargPtr;
 
-template <int MAXR, int NCG>
-__global__ __launch_bounds__(TZ_THREADS, TZ_MINWAVES) void tz_ipm_kernel(IpmParams p) {
+// MINW = workgroups the kernel is compiled to fit on one CU's register file (4: 128 VGPRs; 2: 256; 1: 512).  Problems whose
+// LDS footprint allows fewer than four workgroups per CU anyway get the variant with the larger register budget (no spills).
+template <int MAXR, int NCG, int MINW = TZ_MINWAVES>
+__global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
 #if TZ_PROFILE
   const bool PROF = p.prof != nullptr && blockIdx.x == 0;
 #else

@@ -101,11 +101,18 @@ struct DevCsr {          // device copy of a tz_affmap (CSR in the ABI) re-laid 
 enum { K_TUBE = 0, K_IPM = 1, K_FINISH = 2, K_PLANT = 3, K_COUNT = 4 };
 
 typedef void (*ipm_fn_t)(IpmParams);
-template <int R> ipm_fn_t ipm_pick_ncg(int ncg) {
-  switch (ncg) { case 1: return tz_ipm_kernel<R, 1>; case 2: return tz_ipm_kernel<R, 2>; case 3: return tz_ipm_kernel<R, 3>; default: return tz_ipm_kernel<R, 4>; }
+template <int R, int W> ipm_fn_t ipm_pick_ncg(int ncg) {
+  // one column group (nz <= 64) always fits four workgroups per CU: only the 128-register variant exists for it
+  switch (ncg) { case 1: return tz_ipm_kernel<R, 1, TZ_MINWAVES>; case 2: return tz_ipm_kernel<R, 2, W>; case 3: return tz_ipm_kernel<R, 3, W>; default: return tz_ipm_kernel<R, 4, W>; }
 }
-ipm_fn_t ipm_kernel_for(int maxr, int ncg) {
-  switch (maxr) { case 1: return ipm_pick_ncg<1>(ncg); case 2: return ipm_pick_ncg<2>(ncg); case 3: return ipm_pick_ncg<3>(ncg); default: return ipm_pick_ncg<4>(ncg); }
+template <int W> ipm_fn_t ipm_pick_maxr(int maxr, int ncg) {
+  switch (maxr) { case 1: return ipm_pick_ncg<1, W>(ncg); case 2: return ipm_pick_ncg<2, W>(ncg); case 3: return ipm_pick_ncg<3, W>(ncg); default: return ipm_pick_ncg<4, W>(ncg); }
+}
+// wgs_per_cu: how many workgroups of this problem fit in one CU's LDS (the register budget is chosen to match)
+ipm_fn_t ipm_kernel_for(int maxr, int ncg, int wgs_per_cu) {
+  if (wgs_per_cu >= 4) return ipm_pick_maxr<4>(maxr, ncg);
+  if (wgs_per_cu >= 2) return ipm_pick_maxr<2>(maxr, ncg);
+  return ipm_pick_maxr<1>(maxr, ncg);
 }
 
 }  // namespace
@@ -502,7 +509,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (p->lds_bytes > 160 * 1024)
     TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
   p->maxr = (mi + TZ_THREADS - 1) / TZ_THREADS; p->ncg = (nzp + 63) / 64;
-  p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg);
+  p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg, (int)((160 * 1024) / std::max<size_t>(p->lds_bytes, 1)));
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
   if (const char* e = getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
   if (p->prof && !TZ_PROFILE) TZ_FAIL(TZ_ERR_INVALID, "TZ_PROF=1 needs the diagnostic build of the library (libtzddpc_hip_prof.so)");
