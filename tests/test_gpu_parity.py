@@ -230,6 +230,30 @@ def test_horizon_sweep_against_c_oracle(built, case):
     np.testing.assert_allclose(dev["cost"], ref["cost"], rtol=1e-7, atol=1e-7)
 
 
+def test_infeasible_trajectories_are_flagged_not_fatal(built, monkeypatch):
+    """A start outside the feasible set gives that trajectory the sticky status 3 (the reference raises 'Problem is unbounded',
+    tzddpc/tzddpc.py:374-375) and leaves the others of the batch untouched; same in the one-launch and the four-kernel shape."""
+    from tzddpc_amd.dist import vertex_noise
+    monkeypatch.delenv("TZ_FUSE", raising=False)
+    fused, (A, B, zon) = common.gpu_controller("di_n20")
+    monkeypatch.setenv("TZ_FUSE", "0")
+    split, _ = common.gpu_controller("di_n20")
+    monkeypatch.delenv("TZ_FUSE", raising=False)
+    Bn, T = 16, 6
+    x0 = np.tile(zon.X0.center, (Bn, 1))
+    x0[3] = [50.0, 0.0]; x0[11] = [-40.0, 9.0]
+    noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
+    a = fused.simulate_batch(x0, noise, A, B); b = split.simulate_batch(x0, noise, A, B)
+    bad = np.zeros(Bn, bool); bad[[3, 11]] = True
+    for r in (a, b):
+        assert (r["status"][bad] == 3).all() and (r["status"][~bad] == 0).all()
+        assert np.isinf(r["cost"][bad, 0]).all() and np.isfinite(r["cost"][~bad]).all()
+    np.testing.assert_allclose(a["x"][~bad], b["x"][~bad], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(a["x"][bad], b["x"][bad], rtol=1e-12, atol=1e-9)
+    good_alone = fused.simulate_batch(x0[~bad], noise[~bad], A, B)
+    np.testing.assert_array_equal(good_alone["x"], a["x"][~bad])          # trajectories do not influence each other
+
+
 def test_reference_example_loop_runs_unchanged(built):
     """examples/di_closed_loop.py = reference examples/1.double_integrator_sim.py:20-95 with only the imports changed."""
     import importlib.util
