@@ -27,10 +27,27 @@ class Desc(C.Structure):
                 ("warm_floor", C.c_double), ("warm_gain", C.c_double), ("mu_tol", C.c_double), ("aff_thr", C.c_double), ("aff_mu", C.c_double)]
 
 
+def _cpu_tag() -> str:
+    """Identity of the host CPU: the library is built with -march=native, so a copy built elsewhere must not be loaded blindly."""
+    try:
+        import hashlib
+        with open("/proc/cpuinfo") as f:
+            txt = f.read()
+        model = next((ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("model name")), "?")
+        flags = next((ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("flags")), "")
+        return model + " " + hashlib.sha1(flags.encode()).hexdigest()[:12]
+    except OSError:
+        return "unknown"
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "c", "tz_oracle.c")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "c")] + (["-B"] if force else []), check=True)
+    tag = os.path.join(_HERE, "_build", "cpu.txt")
+    same_cpu = os.path.exists(tag) and open(tag).read() == _cpu_tag()
+    if force or not same_cpu or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.run(["make", "-s", "-B", "-C", os.path.join(_HERE, "c")], check=True)
+        with open(tag, "w") as f:
+            f.write(_cpu_tag())
     return LIB
 
 
@@ -40,8 +57,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            build()
+        build()                      # no-op when the library is current and was built on this CPU
         _lib = C.CDLL(LIB)
         _lib.tzo_max_threads.restype = C.c_int
     return _lib
