@@ -487,14 +487,12 @@ __device__ inline void tz_factor_col(int Tz, double* Hq, double* dinv, int* flag
     const double m31 = -(l31 * i11 + l32 * m21) * i33;
     const double m30 = -(l30 * i00 + l31 * m10 + l32 * m20) * i33;
     if (tid == 0 && !ok) *flag = 1;
-    if (tid < 16) {                       // dinv[pp] = M (lower triangular inverse of the diagonal factor), one entry per lane
-      const int r = tid >> 2, c = tid & 3;
-      double v = 0.0;
-      v = (r == 0 && c == 0) ? i00 : v; v = (r == 1 && c == 0) ? m10 : v; v = (r == 1 && c == 1) ? i11 : v;
-      v = (r == 2 && c == 0) ? m20 : v; v = (r == 2 && c == 1) ? m21 : v; v = (r == 2 && c == 2) ? i22 : v;
-      v = (r == 3 && c == 0) ? m30 : v; v = (r == 3 && c == 1) ? m31 : v; v = (r == 3 && c == 2) ? m32 : v;
-      v = (r == 3 && c == 3) ? i33 : v;
-      dinv[pp * 16 + tid] = v;
+    if (tid == 0) {                       // dinv[pp] = M (lower triangular inverse of the diagonal factor); the six zeros above the
+      double* m = dinv + pp * 16;         // diagonal are written once per launch by the kernel and never touched again
+      m[0] = i00;
+      m[4] = m10; m[5] = i11;
+      m[8] = m20; m[9] = m21; m[10] = i22;
+      m[12] = m30; m[13] = m31; m[14] = m32; m[15] = i33;
     }
   }
   if (pacc) { unsigned long long tq1 = __builtin_amdgcn_s_memtime(); pacc[PH_CH_DIAG] += tq1 - tq0; tq0 = tq1; }
@@ -845,6 +843,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
 #pragma unroll
   for (int k = 0; k < MAXR; ++k) { s_[k] = 1.0; l_[k] = 0.0; h_[k] = 0.0; gx_[k] = 0.0; }
   for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
+  for (int c = t; c < p.Tz * 16; c += TZ_THREADS) dinv[c] = 0.0;
   __syncthreads();
 
   const int nsteps = fused ? F0.nsteps : 1;
