@@ -52,7 +52,7 @@ def cpu_baseline(ctl, A, B, zon, horizon, warmup, steps, seconds_budget=40.0):
     so the rate covers the same steps as the GPU number."""
     from oracle.c_oracle import COracle
     from tzddpc_amd.dist import vertex_noise
-    co = COracle(ctl.qp)
+    co = COracle(ctl.qp, shift_policy=ctl.warm_shift_policy)        # same warm-start policy as the device chose at build time
     cores = max(1, min(os.cpu_count() or 1, COracle.max_threads(), 16))
     Wv = zon.W.compute_vertices()
     T = warmup + steps
@@ -183,7 +183,7 @@ def main():
             "config": {"workload": f"double integrator n=2 m=1, horizon N={args.horizon}, full build_problem, {Bl} closed-loop trajectories per GPU "
                                    f"(BASELINE.json configs[1]), complexity-script zonotopes, vertex-of-W noise PCG64(1000+i)",
                        "trajectories_per_gpu": Bl, "horizon": args.horizon, "nz": ctl.qp.nz, "rows": int(nat.mi),
-                       "ipm_factorizations_per_trajectory_step": iters_mean, "warm_start": os.environ.get("TZ_WARM", "1") != "0", "unsolved_trajectory_steps": int(nbad.item()),
+                       "ipm_factorizations_per_trajectory_step": iters_mean, "warm_start": os.environ.get("TZ_WARM", "1") != "0", "warm_shift_policy": int(ctl.warm_shift_policy), "unsolved_trajectory_steps": int(nbad.item()),
                        "kernel_ms_per_step": {"tz_tube+affine": prep_ms / K, "tz_ipm": ipm_ms / K, "tz_finish": fin_ms / K, "tz_plant": plant_ms / K},
                        "steps_per_launch": K / max(ipm_n, 1)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TZ_ABI_VERSION 1
+#define TZ_ABI_VERSION 2
 
 typedef enum tz_status {
   TZ_OK = 0,
@@ -107,6 +107,13 @@ typedef struct tz_problem_desc {
   double tol;               /* scaled residual / complementarity tolerance */
   double reg;               /* static diagonal regularisation of the reduced Newton matrix */
   double step_frac;         /* fraction of the step to the boundary */
+  /* receding-horizon shift of the warm start of closed-loop steps (all four may be NULL: never shift).  Variable c starts from
+   * x_prev[shift_var[c]] * shift_xscale[c], the multiplier of row r from lambda_prev[shift_row[r]] * shift_lscale[r] (the scales
+   * undo / redo the equilibration of the source and target).  Whether a step shifts is the policy of tz_problem_set_warm_shift. */
+  const int32_t* shift_var;     /* nz */
+  const int32_t* shift_row;     /* mi */
+  const double* shift_xscale;   /* nz */
+  const double* shift_lscale;   /* mi */
 } tz_problem_desc;
 
 typedef struct tz_problem tz_problem;
@@ -166,6 +173,11 @@ int tz_mpc_step(tz_problem* p, int32_t B, double* x, double* xbar, double* e, co
  * the values of the last step; status is the sticky first non-zero status.  Same results as K calls of tz_mpc_step. */
 int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, double* e, const double* w,
                const double* A_true, const double* B_true, double* u_out, double* cost, int32_t* status);
+
+/* Warm-start shift policy of the closed-loop entry points: 0 never (default), 1 every warm-started step, k >= 2 only the steps
+ * that follow a step of at least k interior-point iterations (the transient).  Which one pays depends on the problem (double
+ * integrator N=20: 1; pulley: 0) -- the Python layer calibrates it on a short simulated closed loop at build time. */
+int tz_problem_set_warm_shift(tz_problem* p, int32_t policy);
 
 /* Kernel timing with HIP events on the problem's stream (bench.py roofline leg).
  * kernel ids: 0 = tz_prepare, 1 = tz_ipm, 2 = tz_finish, 3 = tz_plant_step */

@@ -39,12 +39,15 @@ typedef struct tzo_desc {
   double warm_floor, warm_gain;   /* closed-loop warm start (tzo_simulate_batch): see ipm() */
   double mu_tol;                  /* complementarity target (<= tol) */
   double aff_thr, aff_mu;         /* predictor step taken as the step when it is (nearly) full and leaves mu_aff <= aff_mu mu */
+  const int32_t *shift_var, *shift_row;   /* receding-horizon shift of the warm start: source variable (nz) / two-sided row (nc) */
+  int32_t shift_policy;           /* 0 never, 1 always, k >= 2: after a step of >= k iterations (tz_problem_set_warm_shift) */
 } tzo_desc;
 
 typedef struct {
   int nz, mi;
   double *P, *G, *D, *E; double c;
   int *row, *sgn;                 /* one-sided row -> (two-sided row, +1 upper / -1 lower) */
+  int *srow;                      /* one-sided source row of the shifted warm start (NULL without shift maps) */
 } setup_t;
 
 static void ruiz(int nz, int mi, double* P, double* G, double* D, double* E, int iters) {
@@ -94,10 +97,18 @@ static setup_t* make_setup(const tzo_desc* d) {
   }
   S->c = 1.0 / fmax(fmax(pn, qn), 1e-300);
   for (int i = 0; i < nz * nz; ++i) S->P[i] *= S->c;
+  S->srow = NULL;
+  if (d->shift_row && d->shift_var) {
+    S->srow = (int*)malloc(sizeof(int) * mi);
+    for (int a = 0; a < mi; ++a) {
+      int target = d->shift_row[S->row[a]]; S->srow[a] = a;
+      for (int b2 = 0; b2 < mi; ++b2) if (S->row[b2] == target && S->sgn[b2] == S->sgn[a]) { S->srow[a] = b2; break; }
+    }
+  }
   return S;
 }
 
-static void free_setup(setup_t* S) { free(S->P); free(S->G); free(S->D); free(S->E); free(S->row); free(S->sgn); free(S); }
+static void free_setup(setup_t* S) { free(S->srow); free(S->P); free(S->G); free(S->D); free(S->E); free(S->row); free(S->sgn); free(S); }
 
 /* theta = [xbar0 | |xbar0| | (c_k, rho^x_k, rho^u_k)_k]: literal restatement of the collapsed recursion */
 static void tube_theta(const tzo_desc* d, const double* xbar0, const double* e0, double* th, double* ws) {
@@ -176,12 +187,19 @@ static double max_step(int n, const double* v, const double* dv) {
 /* warm != 0: x / lam hold the previous closed-loop step's solution of this trajectory; the slacks are re-derived for the
  * new h and (s, lam) pushed into the cone by max(warm_floor, warm_gain * largest violation of the new rows). */
 static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const double* h, double* x, double* s, double* lam, int* iters, double* wk, int warm) {
-  /* warm == 2: as warm == 1 and gx (G x of the starting point) is still valid in the work area from the previous step */
+  /* warm == 2: as warm == 1 and gx (G x of the starting point) is still valid in the work area from the previous step;
+   * warm == 3: the previous (x, lambda) moved one step along the horizon first (values move unscaled, hence the D / E ratios) */
   int nz = S->nz, mi = S->mi;
   double* H = wk; double* GW = H + nz * nz;
   double* w = GW + mi * nz; double* rd = w + mi; double* rp = rd + nz; double* r1 = rp + mi;
   double* dx = r1 + nz; double* ds = dx + nz; double* dl = ds + mi; double* t1 = dl + mi; double* gx = t1 + mi; double* gdx = gx + mi; double* rc = gdx + mi;
   if (warm) {
+    if (warm == 3) {
+      for (int c = 0; c < nz; ++c) { int sc = d->shift_var[c]; dx[c] = x[sc] * (S->D[sc] / S->D[c]); }
+      for (int c = 0; c < nz; ++c) x[c] = dx[c];
+      for (int r = 0; r < mi; ++r) { int sr = S->srow[r]; dl[r] = lam[sr] * (S->E[sr] / S->E[r]); }
+      for (int r = 0; r < mi; ++r) lam[r] = dl[r];
+    }
     double viol = 0;
     for (int r = 0; r < mi; ++r) {
       if (warm != 2) { double a = 0; for (int c = 0; c < nz; ++c) a += S->G[r * nz + c] * x[c]; gx[r] = a; }
@@ -344,11 +362,14 @@ int tzo_simulate_batch(const tzo_desc* d, int B, int T, const double* x0, const 
 #pragma omp for schedule(dynamic, 4)
 #endif
     for (int b = 0; b < B; ++b) {
-      int32_t sticky = 0; int prev_ok = 0;
+      int32_t sticky = 0; int prev_ok = 0; int prev_it = 0;
       for (int i = 0; i < n; ++i) { x[i] = x0[(size_t)b * n + i]; xbar[i] = x[i]; e[i] = 0; x_traj[((size_t)b * (T + 1)) * n + i] = x[i]; }
       for (int t = 0; t < T; ++t) {
         int32_t st, it; double c;
-        solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk, prev_ok ? ((t & 7) ? 2 : 1) : 0);   /* x / s / lam (and G x) of the previous step live on in wk */
+        int wmode = prev_ok ? ((t & 7) ? 2 : 1) : 0;               /* x / s / lam (and G x) of the previous step live on in wk */
+        if (prev_ok && S->srow && (d->shift_policy == 1 || (d->shift_policy >= 2 && prev_it >= d->shift_policy))) wmode = 3;
+        solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk, wmode);
+        prev_it = it;
         prev_ok = (st == 0) && d->warm_floor > 0;
         if (!sticky && st) sticky = st;
         if (cost) cost[(size_t)b * T + t] = c;

@@ -112,7 +112,7 @@ def test_closed_loop_golden_and_c_oracle(built):
     noise = vertex_noise(zon.W.compute_vertices(), 0, 64, 15)
     x0 = np.tile(zon.X0.center, (64, 1))
     s1 = ctl2.simulate_batch(x0, noise, A, B)
-    s2 = COracle(ctl2.qp).simulate_batch(x0, noise, A, B, threads=16)
+    s2 = COracle(ctl2.qp, shift_policy=ctl2.warm_shift_policy).simulate_batch(x0, noise, A, B, threads=16)
     assert (s1["status"] == 0).all() and (s2["status"] == 0).all()
     np.testing.assert_allclose(s1["x"], s2["x"], atol=1e-6)
     np.testing.assert_allclose(s1["u"], s2["u"], atol=1e-6)
@@ -223,7 +223,7 @@ def test_horizon_sweep_against_c_oracle(built, case):
     noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
     x0 = np.tile(zon.X0.center, (Bn, 1))
     dev = ctl.simulate_batch(x0, noise, A, B)
-    ref = COracle(ctl.qp).simulate_batch(x0, noise, A, B, threads=16)
+    ref = COracle(ctl.qp, shift_policy=ctl.warm_shift_policy).simulate_batch(x0, noise, A, B, threads=16)
     assert (dev["status"] == 0).all() and (ref["status"] == 0).all()
     np.testing.assert_allclose(dev["x"], ref["x"], atol=1e-6)
     np.testing.assert_allclose(dev["u"], ref["u"], atol=1e-6)

@@ -463,6 +463,25 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
                         tube=tube, row_names=[r[0] for r in qp_rows], var_names=var_names, n_v=N * m)
 
 
+def horizon_shift(qp: ParametricQP):
+    """Receding-horizon shift of a solution: entry c of the first array is the variable whose previous value is the starting
+    guess of variable c one MPC step later (``v[k,i] <- v[k+1,i]``, ``tau[j] <- tau[j+1]`` ...; the last step keeps its own),
+    the second array does the same for the (two-sided) rows, i.e. for the multipliers.  Derived from the step index every name
+    carries first."""
+    import re
+    pat = re.compile(r"^([^\[]*)\[(\d+)(.*)$")
+
+    def one(names):
+        index = {nm: i for i, nm in enumerate(names)}
+        out = np.arange(len(names), dtype=np.int32)
+        for i, nm in enumerate(names):
+            mt = pat.match(nm)
+            if mt:
+                out[i] = index.get(f"{mt.group(1)}[{int(mt.group(2)) + 1}{mt.group(3)}", i)
+        return out
+    return one(qp.var_names), one(qp.row_names)
+
+
 # ---- host evaluation helpers (used by tests and by the literal Ze[1] export; NOT the hot path) ----
 
 def tube_reference(tube: TubeConstants, e0: np.ndarray):

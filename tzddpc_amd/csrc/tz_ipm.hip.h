@@ -49,6 +49,8 @@ struct IpmParams {
   int warm_steps;             // multi-step launches: step k+1 starts from the solution of step k
   int nell;                   // max(eg.VL, et.VL)
   int ntube;                  // doubles of tube tables kept in LDS by fused launches: (pmax + 1) n n + pmax (n + m) n
+  int shift_policy;           // receding-horizon shift of the warm start: 0 never, 1 always, k >= 2 after a step of >= k iterations
+  const int* sx; const int* sr; const double* sxs; const double* sls;   // source variable / row and rescaling, see tz_problem_desc
   int chol1;                  // Tz <= 16: one wave factors H while the other three form the predictor's right-hand side
   int ksplit;                 // Gram by tz_form_H_ksplit (Tz <= TZ_KS_TZ) instead of the item plan
   int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
@@ -913,10 +915,28 @@ retry_solve:
   if (warm) {
     // ---- warm start: previous (x, lambda) of this trajectory, slacks re-derived for the new h and pushed into the cone
     // by at least the amount the old point violates the new rows; a point that is too far outside starts cold instead
-    if (src == 1) { for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + c]; TZ_ROWS(k, r) l_[k] = p.lam[(size_t)b * mi + r]; }
+    // the previous solution, optionally moved one step along the horizon (v_k <- v_{k+1} ...: better in a transient, a matter of
+    // the problem otherwise -- tz_problem_set_warm_shift)
+    const int prev_it = (step == 0) ? p.iters[b] : it;
+    const bool shifted = p.shift_policy == 1 || (p.shift_policy >= 2 && prev_it >= p.shift_policy);
+    if (src == 1) {
+      if (shifted) {
+        for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + p.sx[c]] * p.sxs[c];
+        TZ_ROWS(k, r) l_[k] = p.lam[(size_t)b * mi + p.sr[r]] * p.sls[r];
+      } else {
+        for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + c];
+        TZ_ROWS(k, r) l_[k] = p.lam[(size_t)b * mi + r];
+      }
+    } else if (shifted) {                                   // src == 2: x in LDS, lambda in registers of the row owners
+      for (int c = t; c < nz; c += TZ_THREADS) tmpz[c] = xv[p.sx[c]] * p.sxs[c];
+      TZ_ROWS(k, r) vin[r] = l_[k];
+      __syncthreads();
+      for (int c = t; c < nz; c += TZ_THREADS) xv[c] = tmpz[c];
+      TZ_ROWS(k, r) l_[k] = vin[p.sr[r]] * p.sls[r];
+    }
     // G x of the starting point: inside a launch gx_ still holds it (it followed x through the iterations of the previous
     // step); it is formed afresh every eighth step so that rounding does not accumulate along a trajectory
-    if (src != 2 || (step & 7) == 0 || retried) tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
+    if (src != 2 || (step & 7) == 0 || retried || shifted) tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
     double viol = 0.0;
     TZ_ROWS(k, r) { viol = fmax(viol, gx_[k] - h_[k]); sch = fmax(sch, fabs(h_[k])); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));

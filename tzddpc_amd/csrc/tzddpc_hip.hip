@@ -125,7 +125,10 @@ struct tz_problem {
   double tol = 1e-10, reg = 1e-12, step_frac = 0.99, cost_scale = 1.0, r0 = 0.0;
   // constants
   DevBuf<double> P, G, Gt, Gp, act_scale, Dz, Phi, Gam, r1, R2, CK, DK, K, CKpow, Ttube, par_lo, par_hi;
-  DevBuf<int> power, row_of, klist, item_ptr, smask;
+  DevBuf<int> power, row_of, klist, item_ptr, smask, shift_var, shift_row;
+  DevBuf<double> shift_xs, shift_ls;
+  int shift_policy = 0;        // 0 never, 1 always, k >= 2: after a step of >= k iterations (tz_problem_set_warm_shift)
+  bool have_shift = false;
   DevBuf<IpmItem> items;
   DevCsr q, h, par;
   DevEll eg, et;
@@ -236,6 +239,8 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.prof = p->prof ? p->prof_buf.p : nullptr;
   ip.work = p->timing ? p->work_buf.p : nullptr;
   ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0; ip.chol1 = p->chol1 ? 1 : 0; ip.ntube = p->ntube;
+  ip.shift_policy = p->have_shift ? p->shift_policy : 0;
+  ip.sx = p->shift_var.p; ip.sr = p->shift_row.p; ip.sxs = p->shift_xs.p; ip.sls = p->shift_ls.p;
   ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
   ip.warm_gain = p->warm_gain; ip.aff_thr = p->aff_thr; ip.aff_mu = p->aff_mu;
   ip.prev_status = warm ? p->prev_status.p : nullptr;
@@ -496,6 +501,13 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   }
   TZ_HIP(p->power.upload(d->power, (size_t)d->N));
   TZ_HIP(p->row_of.upload(d->row_of, (size_t)mi));
+  if (d->shift_var && d->shift_row && d->shift_xscale && d->shift_lscale) {
+    for (int c = 0; c < nz; ++c) if (d->shift_var[c] < 0 || d->shift_var[c] >= nz) TZ_FAIL(TZ_ERR_INVALID, "shift_var[%d] out of range", c);
+    for (int r = 0; r < mi; ++r) if (d->shift_row[r] < 0 || d->shift_row[r] >= mi) TZ_FAIL(TZ_ERR_INVALID, "shift_row[%d] out of range", r);
+    TZ_HIP(p->shift_var.upload(d->shift_var, (size_t)nz)); TZ_HIP(p->shift_row.upload(d->shift_row, (size_t)mi));
+    TZ_HIP(p->shift_xs.upload(d->shift_xscale, (size_t)nz)); TZ_HIP(p->shift_ls.upload(d->shift_lscale, (size_t)mi));
+    p->have_shift = true;
+  }
   TZ_HIP(p->act_scale.upload(d->act_scale, (size_t)mi));
 
   p->ksplit = (p->Tz <= TZ_KS_TZ);
@@ -690,6 +702,14 @@ int tz_simulate_batch(tz_problem* p, int32_t B, int32_t T, const double* x0, con
   } else {
     TZ_HIP(hipMemcpyAsync(status, p->sticky.p, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, st));
   }
+  return TZ_OK;
+}
+
+int tz_problem_set_warm_shift(tz_problem* p, int32_t policy) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  if (policy < 0) TZ_FAIL(TZ_ERR_INVALID, "policy must be >= 0");
+  if (policy != 0 && !p->have_shift) TZ_FAIL(TZ_ERR_INVALID, "the problem was created without shift maps");
+  p->shift_policy = policy;
   return TZ_OK;
 }
 

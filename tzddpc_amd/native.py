@@ -11,7 +11,7 @@ from typing import Optional
 
 import numpy as np
 
-TZ_ABI_VERSION = 1
+TZ_ABI_VERSION = 2
 TZ_MEM_HOST, TZ_MEM_DEVICE = 0, 1
 TZ_SOLVED, TZ_MAX_ITER, TZ_NUMERICAL, TZ_INFEASIBLE = 0, 1, 2, 3
 
@@ -43,6 +43,7 @@ class ProblemDesc(C.Structure):
         ("nc_rows", C.c_int32), ("row_of", _ip), ("act_scale", _dp),
         ("CK", _dp), ("DK", _dp), ("K", _dp), ("pmax", C.c_int32), ("absCKpow", _dp), ("absKCKpow", _dp), ("power", _ip),
         ("max_iter", C.c_int32), ("tol", C.c_double), ("reg", C.c_double), ("step_frac", C.c_double),
+        ("shift_var", _ip), ("shift_row", _ip), ("shift_xscale", _dp), ("shift_lscale", _dp),
     ]
 
 
@@ -100,7 +101,8 @@ def lib():
 
 EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy",
                     "tz_problem_set_stream", "tz_problem_sync", "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run",
-                    "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch")
+                    "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch",
+                    "tz_problem_set_warm_shift")
 
 
 def check(rc: int, what: str):
@@ -151,7 +153,8 @@ class Problem:
 
     def __init__(self, device: int, *, n, m, N, P, G, q0, Qt, h0, Ht, par0, Part, par_lo, par_hi, cost_scale, r0, r1, R2,
                  Dz, Phi, Gam, nc_rows, row_of, act_scale, CK, DK, K, pmax, absCKpow, absKCKpow, power,
-                 max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999):
+                 max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999,
+                 shift_var=None, shift_row=None, shift_xscale=None, shift_lscale=None):
         L = lib()
         keep = []
         d = ProblemDesc()
@@ -173,6 +176,10 @@ class Problem:
         d.nc_rows = int(nc_rows); d.row_of = _ptr(ro, _ip)
         d.pmax = int(pmax); d.power = _ptr(pw, _ip)
         d.max_iter = int(max_iter); d.tol = float(tol); d.reg = float(reg); d.step_frac = float(step_frac)
+        if shift_var is not None:
+            sv, sr, xs, ls = _i32(shift_var), _i32(shift_row), _f64(shift_xscale), _f64(shift_lscale)
+            keep += [sv, sr, xs, ls]
+            d.shift_var = _ptr(sv, _ip); d.shift_row = _ptr(sr, _ip); d.shift_xscale = _ptr(xs, _dp); d.shift_lscale = _ptr(ls, _dp)
         self.n, self.m, self.N, self.nz, self.mi, self.nc_rows, self.ntheta = int(n), int(m), int(N), d.nz, d.mi, int(nc_rows), d.ntheta
         # structure-aware algorithmic work of one interior-point factorisation + its two solves (what bench.py's roofline
         # counts): sparse outer products of the rows of G, Cholesky, four G / G' products, two triangular solve pairs, P x
@@ -241,6 +248,9 @@ class Problem:
 
     def sync(self):
         check(lib().tz_problem_sync(self._h), "tz_problem_sync")
+
+    def set_warm_shift(self, policy: int):
+        check(lib().tz_problem_set_warm_shift(self._h, int(policy)), "tz_problem_set_warm_shift")
 
     def timing_enable(self, on: bool = True):
         check(lib().tz_timing_enable(self._h, int(on)), "tz_timing_enable")
