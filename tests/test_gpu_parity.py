@@ -254,6 +254,32 @@ def test_infeasible_trajectories_are_flagged_not_fatal(built, monkeypatch):
     np.testing.assert_array_equal(good_alone["x"], a["x"][~bad])          # trajectories do not influence each other
 
 
+def test_warm_shift_policies_agree(built):
+    """The receding-horizon shift of the warm start changes the number of iterations, not the trajectories; the C oracle follows
+    the same policy step by step."""
+    from oracle.c_oracle import COracle
+    from tzddpc_amd.dist import vertex_noise
+    ctl, (A, B, zon) = common.gpu_controller("di_n20")
+    assert ctl.warm_shift_policy in (0, 3)
+    Bn, T = 64, 24
+    noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
+    x0 = np.tile(zon.X0.center, (Bn, 1))
+    runs, work = {}, {}
+    for pol in (0, 1, 3):
+        ctl._native.set_warm_shift(pol)
+        ctl._native.timing_enable(True)
+        runs[pol] = ctl.simulate_batch(x0, noise, A, B)
+        work[pol] = ctl._native.work_get()["factorizations"]
+        ctl._native.timing_enable(False)
+        assert (runs[pol]["status"] == 0).all()
+        ref = COracle(ctl.qp, shift_policy=pol).simulate_batch(x0, noise, A, B, threads=16)
+        np.testing.assert_allclose(runs[pol]["x"], ref["x"], atol=1e-6)
+    ctl._native.set_warm_shift(ctl.warm_shift_policy)
+    np.testing.assert_allclose(runs[1]["x"], runs[0]["x"], atol=1e-6)
+    np.testing.assert_allclose(runs[3]["x"], runs[0]["x"], atol=1e-6)
+    assert work[3] < work[0]                      # the transient from X0 is what the shift is for
+
+
 def test_reference_example_loop_runs_unchanged(built):
     """examples/di_closed_loop.py = reference examples/1.double_integrator_sim.py:20-95 with only the imports changed."""
     import importlib.util

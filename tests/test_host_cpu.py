@@ -178,3 +178,16 @@ def test_gather_results_world_size_2_gloo(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
+
+
+def test_horizon_shift_maps():
+    """Shift maps derived from the variable / row names: v[k] <- v[k+1], tau[j] <- tau[j+1], the last step keeps its own."""
+    from tzddpc_amd.builder import horizon_shift
+    _, qp, _ = common.identified_qp("di_n20")
+    sv, sr = horizon_shift(qp)
+    names = qp.var_names
+    assert names[sv[names.index("v[3,0]")]] == "v[4,0]" and names[sv[names.index("v[19,0]")]] == "v[19,0]"
+    assert names[sv[names.index("tau[5]")]] == "tau[6]"
+    rows = qp.row_names
+    assert rows[sr[rows.index("Xub[4,1]")]] == "Xub[5,1]" and rows[sr[rows.index("tau[3]+-+")]] == "tau[4]+-+"
+    assert len(set(sv.tolist())) == len(sv) - 2           # only the two last-step variables are the target of two sources
