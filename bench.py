@@ -67,7 +67,13 @@ def cpu_baseline(ctl, A, B, zon, horizon, warmup, steps, seconds_budget=40.0):
     d_all, out = timed(traj, T)
     d_warm = timed(traj, warmup)[0] if warmup > 0 else 0.0
     dt = max(d_all - d_warm, 1e-9)
-    return {"value": traj * steps / dt, "unit": "MPC steps/s", "cores": cores, "kind": "port",
+    # one thread, for scale (SURVEY section 8d asks for both)
+    t1 = max(32, traj // (8 * cores))
+    x1 = np.tile(zon.X0.center, (t1, 1)); n1 = vertex_noise(Wv, 0, t1, T)
+    t0 = time.perf_counter(); co.simulate_batch(x1, n1, A, B, threads=1); e_all = time.perf_counter() - t0
+    t0 = time.perf_counter(); co.simulate_batch(x1, n1[:, :warmup], A, B, threads=1); e_warm = (time.perf_counter() - t0) if warmup > 0 else 0.0
+    one = t1 * steps / max(e_all - e_warm, 1e-9)
+    return {"value": traj * steps / dt, "unit": "MPC steps/s", "cores": cores, "kind": "port", "value_one_thread": one,
             "sample": f"{traj} trajectories x closed-loop steps {warmup}..{T - 1} of the same DI N={horizon} workload (time of {T} steps minus time of the "
                       f"first {warmup}), plain-C oracle with the same warm-started interior point, OpenMP over trajectories, {d_all + d_warm:.1f} s wall, "
                       f"all statuses zero: {bool((out['status'] == 0).all())}"}
