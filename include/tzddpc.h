@@ -175,7 +175,8 @@ int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, dou
                const double* A_true, const double* B_true, double* u_out, double* cost, int32_t* status);
 
 /* Warm-start shift policy of the closed-loop entry points: 0 never (default), 1 every warm-started step, k >= 2 only the steps
- * that follow a step of at least k interior-point iterations (the transient).  Which one pays depends on the problem (double
+ * that follow a step of at least k interior-point iterations (the transient) and, after those, for as long as the shifted steps
+ * finish in one iteration.  Which one pays depends on the problem (double
  * integrator N=20: 1; pulley: 0) -- the Python layer calibrates it on a short simulated closed loop at build time. */
 int tz_problem_set_warm_shift(tz_problem* p, int32_t policy);
 

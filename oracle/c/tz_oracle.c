@@ -40,7 +40,8 @@ typedef struct tzo_desc {
   double mu_tol;                  /* complementarity target (<= tol) */
   double aff_thr, aff_mu;         /* predictor step taken as the step when it is (nearly) full and leaves mu_aff <= aff_mu mu */
   const int32_t *shift_var, *shift_row;   /* receding-horizon shift of the warm start: source variable (nz) / two-sided row (nc) */
-  int32_t shift_policy;           /* 0 never, 1 always, k >= 2: after a step of >= k iterations (tz_problem_set_warm_shift) */
+  int32_t shift_policy;           /* 0 never, 1 always, k >= 2: after a step of >= k iterations and while the shifted steps that
+                                   * follow take one iteration (tz_problem_set_warm_shift) */
 } tzo_desc;
 
 typedef struct {
@@ -362,12 +363,13 @@ int tzo_simulate_batch(const tzo_desc* d, int B, int T, const double* x0, const 
 #pragma omp for schedule(dynamic, 4)
 #endif
     for (int b = 0; b < B; ++b) {
-      int32_t sticky = 0; int prev_ok = 0; int prev_it = 0;
+      int32_t sticky = 0; int prev_ok = 0; int prev_it = 0; int was_shifted = 0;
       for (int i = 0; i < n; ++i) { x[i] = x0[(size_t)b * n + i]; xbar[i] = x[i]; e[i] = 0; x_traj[((size_t)b * (T + 1)) * n + i] = x[i]; }
       for (int t = 0; t < T; ++t) {
         int32_t st, it; double c;
         int wmode = prev_ok ? ((t & 7) ? 2 : 1) : 0;               /* x / s / lam (and G x) of the previous step live on in wk */
-        if (prev_ok && S->srow && (d->shift_policy == 1 || (d->shift_policy >= 2 && prev_it >= d->shift_policy))) wmode = 3;
+        if (prev_ok && S->srow && (d->shift_policy == 1 || (d->shift_policy >= 2 && (prev_it >= d->shift_policy || (was_shifted && prev_it <= 1))))) wmode = 3;
+        was_shifted = (wmode == 3);
         solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk, wmode);
         prev_it = it;
         prev_ok = (st == 0) && d->warm_floor > 0;

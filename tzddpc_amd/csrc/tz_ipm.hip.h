@@ -50,6 +50,8 @@ struct IpmParams {
   int nell;                   // max(eg.VL, et.VL)
   int ntube;                  // doubles of tube tables kept in LDS by fused launches: (pmax + 1) n n + pmax (n + m) n
   int shift_policy;           // receding-horizon shift of the warm start: 0 never, 1 always, k >= 2 after a step of >= k iterations
+                              // and for as long as the shifted steps that follow finish in one iteration
+  int* shift_state;           // per trajectory: was the last warm start shifted (carried across launches)
   const int* sx; const int* sr; const double* sxs; const double* sls;   // source variable / row and rescaling, see tz_problem_desc
   int chol1;                  // Tz <= 16: one wave factors H while the other three form the predictor's right-hand side
   int ksplit;                 // Gram by tz_form_H_ksplit (Tz <= TZ_KS_TZ) instead of the item plan
@@ -849,6 +851,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   __syncthreads();
 
   const int nsteps = fused ? F0.nsteps : 1;
+  int was_shifted = (p.shift_policy >= 2 && p.warm != 0) ? p.shift_state[b] : 0;
   int status = 1, it = 0;
   unsigned long long work_f = 0, work_s = 0;
   for (int step = 0; step < nsteps; ++step) {     // closed-loop steps of this trajectory (one when the launch is a single solve)
@@ -918,7 +921,8 @@ retry_solve:
     // the previous solution, optionally moved one step along the horizon (v_k <- v_{k+1} ...: better in a transient, a matter of
     // the problem otherwise -- tz_problem_set_warm_shift)
     const int prev_it = (step == 0) ? p.iters[b] : it;
-    const bool shifted = p.shift_policy == 1 || (p.shift_policy >= 2 && prev_it >= p.shift_policy);
+    const bool shifted = p.shift_policy == 1 || (p.shift_policy >= 2 && (prev_it >= p.shift_policy || (was_shifted != 0 && prev_it <= 1)));
+    was_shifted = shifted ? 1 : 0;
     if (src == 1) {
       if (shifted) {
         for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + p.sx[c]] * p.sxs[c];
@@ -948,6 +952,7 @@ retry_solve:
     }
   }
   if (!warm) {
+    was_shifted = 0;
     // ---- cold start: (P + G'G + reg) x = -q + G'h, then shift the slacks into the cone
     tz_gram(p, Hq, Pq, vin, kl);
     __syncthreads();
@@ -1131,6 +1136,7 @@ retry_solve:
     TZ_ROWS(k, r) { p.s[(size_t)b * mi + r] = s_[k]; p.lam[(size_t)b * mi + r] = l_[k]; }
     if (t == 0) {
       p.status[b] = status; p.iters[b] = it;
+      if (p.shift_policy >= 2) p.shift_state[b] = was_shifted;
       if (p.status_copy) p.status_copy[b] = status;
       if (p.work) { atomicAdd(p.work, work_f); atomicAdd(p.work + 1, work_s); }
     }

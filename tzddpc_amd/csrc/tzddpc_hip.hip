@@ -138,7 +138,7 @@ struct tz_problem {
   // workspace (capacity Bcap)
   int Bcap = 0;
   DevBuf<double> theta, qv, hv, x, s, lam, v, xbar, cost, in_x0, in_e0;
-  DevBuf<int> prestatus, status, iters, sticky, prev_status;
+  DevBuf<int> prestatus, status, iters, sticky, prev_status, shift_state;
   DevBuf<uint8_t> active;
   // closed-loop state / plant (simulate)
   DevBuf<double> st_x, st_xbar, st_e, plantA, plantB, noise, xtraj, utraj, costtraj;
@@ -186,6 +186,8 @@ int ensure_workspace(tz_problem* p, int B) {
   TZ_HIP(p->iters.alloc(b));
   TZ_HIP(p->sticky.alloc(b));
   TZ_HIP(p->prev_status.alloc(b));
+  TZ_HIP(p->shift_state.alloc(b));
+  TZ_HIP(hipMemset(p->shift_state.p, 0, b * sizeof(int)));
   TZ_HIP(p->active.alloc(b * std::max(p->nc_rows, 1)));
   TZ_HIP(p->st_x.alloc(b * p->n));
   TZ_HIP(p->st_xbar.alloc(b * p->n));
@@ -240,6 +242,7 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.work = p->timing ? p->work_buf.p : nullptr;
   ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0; ip.chol1 = p->chol1 ? 1 : 0; ip.ntube = p->ntube;
   ip.shift_policy = p->have_shift ? p->shift_policy : 0;
+  ip.shift_state = p->shift_state.p;
   ip.sx = p->shift_var.p; ip.sr = p->shift_row.p; ip.sxs = p->shift_xs.p; ip.sls = p->shift_ls.p;
   ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
   ip.warm_gain = p->warm_gain; ip.aff_thr = p->aff_thr; ip.aff_mu = p->aff_mu;
