@@ -221,8 +221,8 @@ class TZDDPC(object):
     def _choose_warm_shift(self, mode, A_model, B_model) -> int:
         """Warm-start policy of the closed-loop entry points (``tz_problem_set_warm_shift``): ``"off"`` / 0, ``"on"`` / 1, an
         integer k >= 2 (shift after steps of >= k iterations) or ``"auto"``: a 48-step closed loop of the identified model from
-        the centre of X0 under vertex noise is run on the device without shifting and with shifting after steps of >= 3
-        iterations (i.e. in transients only), and the one with fewer factorisations is kept (double integrators gain ~20 %
+        the centre of X0 under vertex noise is run on the device without shifting and with policy 3 (shift after a step of >= 3
+        iterations and while the shifted steps that follow take one iteration), and the one with fewer factorisations is kept (double integrators gain ~20 %
         from shifting, the pulley and the simplified problems lose 25-100 %)."""
         nat = self._native
         if mode in ("off", 0, False, None):
