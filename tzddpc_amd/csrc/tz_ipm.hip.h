@@ -853,7 +853,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   const int nsteps = fused ? F0.nsteps : 1;
   int was_shifted = (p.shift_policy >= 2 && p.warm != 0) ? p.shift_state[b] : 0;
   int status = 1, it = 0;
-  unsigned long long work_f = 0, work_s = 0;
+  int work_f = 0, work_s = 0;                // uniform: kept in scalar registers
   for (int step = 0; step < nsteps; ++step) {     // closed-loop steps of this trajectory (one when the launch is a single solve)
   // start point of this step: 0 cold, 1 the (x, lambda) stored by an earlier launch, 2 the (x, lambda) of the previous step (still
   // in LDS / registers)
@@ -867,9 +867,6 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   TzKargPtr kp0 = (TzKargPtr)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(kp0));
   const FuseParams& F = ((const IpmParams*)kp0)->F;
-  // this step's disturbance is needed only by the plant update at the very end: fetch it now, the round trip hides behind the solve
-  double w_now = 0.0;
-  if (fused && t < F.fin.n) w_now = F.plant.w[(size_t)b * F.plant.w_stride + (size_t)step * F.w_step + t];
   bool skip = false;                        // fused step: a parameter row is violated -> status 3, u = K e, nominal state from Phi
   for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the cold start point
   if (fused) {
@@ -908,7 +905,6 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   // A solve that does not end in TZ_SOLVED (in practice: the aggressive fraction to the boundary collapsing mu before the
   // residuals on a degenerate problem, ~2e-5 of the pulley steps) is repeated once from a cold start with the textbook 0.99.
   int attempt = 0;
-  double sfrac = p.step_frac;
 retry_solve:
   const bool retried = attempt != 0;
   bool okf = true;
@@ -1072,7 +1068,7 @@ retry_solve:
     TZ_ROWS(k, r) muaff += (s_[k] + ap * ds_[k]) * (l_[k] + ad * dl_[k]);
     tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(muaff, z1, z2, red);
     muaff /= mi;
-    const double sfr = sfrac;
+    const double sfr = (attempt == 0) ? p.step_frac : fmin(p.step_frac, 0.99);
     if (fmin(ap, ad) >= p.aff_thr && muaff <= p.aff_mu * mu) {
       // the Newton (predictor) step is already (almost) a full step and kills complementarity: take it, skip the corrector
       const double mmA = fmax(mp, md);
@@ -1119,9 +1115,9 @@ retry_solve:
     __syncthreads();
   }
   TZ_FRESH_T();
-  work_f += (unsigned long long)(it + ((warm || skip) ? 0 : 1));
+  work_f = __builtin_amdgcn_readfirstlane(work_f + it + ((warm || skip) ? 0 : 1));
   if (status != 0 && !skip && attempt == 0) {
-    attempt = 1; src = 0; sfrac = fmin(sfrac, 0.99);
+    attempt = 1; src = 0;
     __syncthreads();
     if (t == 0) flag[0] = 0;
     for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
@@ -1138,7 +1134,7 @@ retry_solve:
       p.status[b] = status; p.iters[b] = it;
       if (p.shift_policy >= 2) p.shift_state[b] = was_shifted;
       if (p.status_copy) p.status_copy[b] = status;
-      if (p.work) { atomicAdd(p.work, work_f); atomicAdd(p.work + 1, work_s); }
+      if (p.work) { atomicAdd(p.work, (unsigned long long)work_f); atomicAdd(p.work + 1, (unsigned long long)work_s); }
     }
   }
   TZ_STAMP(PH_ELEM);
@@ -1192,7 +1188,7 @@ retry_solve:
       const PlantParams& Q = F.plant;
       double xn = 0.0, xb = 0.0;
       if (t < n) {
-        xn = w_now;
+        xn = Q.w[(size_t)b * Q.w_stride + (size_t)step * F.w_step + t];
         for (int j = 0; j < n; ++j) xn += cA[t * n + j] * stl[j];
         for (int j = 0; j < m; ++j) {
           double u = dxv[j];
