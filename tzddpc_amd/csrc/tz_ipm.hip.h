@@ -973,7 +973,9 @@ retry_solve:
     TZ_ROWS(k, r) s_[k] = h_[k] - gx_[k] + shift;
   }
   }
-  const double sc_d = 1.0 + scq, sc_p = 1.0 + sch;
+  // scales of the stopping test: parked in LDS (two spare slots of the reduction buffer) instead of four registers for the whole solve
+  if (t == 0) { red[12] = 1.0 + scq; red[13] = 1.0 + sch; }
+  __syncthreads();
 
   status = skip ? 3 : (okf ? 1 : 2);
   bool px_in_part = false;                  // `part` holds the partial sums of P x for the final x (left there by exact_rd)
@@ -990,14 +992,14 @@ retry_solve:
     TZ_ROWS(k, r) { rp_[k] = gx_[k] + s_[k] - h_[k]; nrp = fmax(nrp, fabs(rp_[k])); sl += s_[k] * l_[k]; }
     tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM>(nrp, sl, z0, red);
     const double mu = sl / mi;
-    nrp /= sc_p;
+    nrp /= red[13];
     if (!(mu == mu) || !(nrp == nrp) || mu > 1e200) { status = 2; break; }
     if ((nrp <= p.tol && mu <= p.mu_tol) || mu <= 1e-3 * p.mu_tol) {
       exact_rd();
       double e1 = 0, e2 = 0, e3 = 0;
       for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
       tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(e1, e2, e3, red);
-      const double nrd = e1 / sc_d;
+      const double nrd = e1 / red[12];
       TZ_STAMP(PH_GEMVT);
       if (!(nrd == nrd)) { status = 2; break; }
       if (nrd <= p.tol && nrp <= p.tol && mu <= p.mu_tol) { status = 0; px_in_part = true; break; }
