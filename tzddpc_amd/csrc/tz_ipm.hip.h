@@ -114,24 +114,29 @@ __device__ inline double tz_wave_reduce(double v) {
   return tz_op<OP>(tz_op<OP>(r0, r1), tz_op<OP>(r2, r3));
 }
 
-// three simultaneous block reductions (ops fixed at compile time); result broadcast to all threads.
-template <int OP0, int OP1, int OP2>
-__device__ inline void tz_block_reduce3(double& a, double& b, double& c, double* red) {
-  a = tz_wave_reduce<OP0>(a); b = tz_wave_reduce<OP1>(b); c = tz_wave_reduce<OP2>(c);
+// up to three simultaneous block reductions (ops fixed at compile time; the first NV of a, b, c take part); result broadcast to
+// all threads.  The exchange buffer alternates between red[0..11] and red[16..27] (`par`, toggled here: every thread makes the
+// same sequence of calls), so one barrier per reduction is enough: a buffer is written again only after the barrier of the
+// reduction in between, which no thread reaches before it has read its values of this one.
+template <int OP0, int OP1, int OP2, int NV = 3>
+__device__ inline void tz_block_reduce3(double& a, double& b, double& c, double* red, int& par) {
+  a = tz_wave_reduce<OP0>(a);
+  if (NV > 1) b = tz_wave_reduce<OP1>(b);
+  if (NV > 2) c = tz_wave_reduce<OP2>(c);
   const int tt = tz_tid();
   int lane = tt & 63, w = tt >> 6;
-  __syncthreads();                       // protect red[] from the previous use
-  if (lane == 0) { red[w] = a; red[4 + w] = b; red[8 + w] = c; }
+  double* rb_ = red + (par ? 16 : 0);
+  par ^= 1;
+  if (lane == 0) { rb_[w] = a; if (NV > 1) rb_[4 + w] = b; if (NV > 2) rb_[8 + w] = c; }
   __syncthreads();
-  double ra = red[0], rb = red[4], rc = red[8];
+  double ra = rb_[0], rb = (NV > 1) ? rb_[4] : 0.0, rc = (NV > 2) ? rb_[8] : 0.0;
 #pragma unroll
   for (int i = 1; i < TZ_NWAVES; ++i) {
-    double va = red[i], vb = red[4 + i], vc = red[8 + i];
-    ra = (OP0 == RED_SUM) ? ra + va : (OP0 == RED_MAX ? fmax(ra, va) : fmin(ra, va));
-    rb = (OP1 == RED_SUM) ? rb + vb : (OP1 == RED_MAX ? fmax(rb, vb) : fmin(rb, vb));
-    rc = (OP2 == RED_SUM) ? rc + vc : (OP2 == RED_MAX ? fmax(rc, vc) : fmin(rc, vc));
+    ra = tz_op<OP0>(ra, rb_[i]);
+    if (NV > 1) rb = tz_op<OP1>(rb, rb_[4 + i]);
+    if (NV > 2) rc = tz_op<OP2>(rc, rb_[8 + i]);
   }
-  a = ra; b = rb; c = rc;
+  a = ra; if (NV > 1) b = rb; if (NV > 2) c = rc;
 }
 
 // part[w][c] = sum over the rows r = w, w+4, ... of M[r][c] in[r]  (row-major M, rows x nzp; `in` in LDS).
@@ -752,8 +757,8 @@ __device__ inline void tz_chol_solve_wave(const IpmParams& p, const double* Hq, 
 }
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
-__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit, int ntube, int nell) {
-  return (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 14 * (size_t)nzp + (size_t)(mip + 4) + 16 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX + (size_t)ntube + (size_t)nell;
+__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit, int ntube, int nell, int park = 0) {
+  return (park ? 2 * (size_t)mip : 0) + (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 14 * (size_t)nzp + (size_t)(mip + 4) + 32 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX + (size_t)ntube + (size_t)nell;
 }
 
 typedef __attribute__((address_space(4))) const IpmParams* TzKargPtr;
@@ -796,17 +801,26 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   double* part = tmpz + nzp;              // 4 * nzp
   double* part2 = part + 4 * nzp;         // 4 * nzp
   double* vin = part2 + 4 * nzp;           // mip + 4 : staging of one row vector (w for the Gram, inputs of G' products)
-  double* red = vin + mip + 4;            // 16
-  int* flag = (int*)(red + 16);
-  int* kl = (int*)(red + 18);
-  double* thl = red + 18 + (p.nklist + 1) / 2;      // theta of this trajectory (fused step only)
+  double* red = vin + mip + 4;            // 32: two exchange buffers of the block reductions (+ the stopping-test scales in [12], [13])
+  int* flag = (int*)(red + 32);
+  int* kl = (int*)(red + 34);
+  double* thl = red + 34 + (p.nklist + 1) / 2;      // theta of this trajectory (fused step only)
   double* stl = thl + p.F.ntheta;                   // fused: closed-loop state [x | xbar | e] (3 TZ_NMAX doubles)
   double* pl = stl + 3 * TZ_NMAX;                   // partial sums of the lane-ELL products (nell doubles)
   double* tbl = pl + p.nell;                  // fused: C_K powers and the tube resolvent (copied once per launch)
   double* Pq = tbl + p.ntube;                       // ksplit: P + reg I in the quad layout of Hq (lower tiles)
+  // 128-register variant: h and G x of the rows live in LDS (each thread touches only its own slots: no barrier) -- two
+  // register pairs fewer across the whole solve
+  constexpr bool PARK = (MINW == 4);
+  double* hL = Pq + (p.ksplit ? (size_t)p.nquads * TZ_QSTR : 0);
+  double* gL = hL + mip;
 
   // rows owned by this thread
-  double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR];        // live across iterations (s, lambda also across steps)
+  double s_[MAXR], l_[MAXR], h_[MAXR], gx_[MAXR];        // live across iterations (s, lambda also across steps); h, gx unused when parked
+#define TZ_H(k, r) (PARK ? hL[r] : h_[k])
+#define TZ_GX(k, r) (PARK ? gL[r] : gx_[k])
+#define TZ_SET_H(k, r, v) do { if (PARK) hL[r] = (v); else h_[k] = (v); } while (0)
+#define TZ_ADD_GX(k, r, v) do { if (PARK) gL[r] += (v); else gx_[k] += (v); } while (0)
 #define TZ_ROWS(k, r) _Pragma("unroll") for (int k = 0; k < MAXR; ++k) if (const int r = t + TZ_THREADS * k; r < mi)
   int rseg_[MAXR];                                   // lanes of the G x product that carry this thread's rows
 #pragma unroll
@@ -854,6 +868,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   int was_shifted = (p.shift_policy >= 2 && p.warm != 0) ? p.shift_state[b] : 0;
   int status = 1, it = 0;
   int work_f = 0, work_s = 0;                // uniform: kept in scalar registers
+  int rpar = 0;                              // which exchange buffer the next block reduction uses
   for (int step = 0; step < nsteps; ++step) {     // closed-loop steps of this trajectory (one when the launch is a single solve)
   // start point of this step: 0 cold, 1 the (x, lambda) stored by an earlier launch, 2 the (x, lambda) of the previous step (still
   // in LDS / registers)
@@ -880,10 +895,10 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
       if (!(v >= F.par_lo[r] - 1e-9) || !(v <= F.par_hi[r] + 1e-9)) bad = 1;
     }
     if (bad) flag[1] = 1;
-    TZ_ROWS(k, r) h_[k] = csr_row(F.hmap, r, thl);
+    TZ_ROWS(k, r) TZ_SET_H(k, r, csr_row(F.hmap, r, thl));
   } else {
     for (int c = t; c < nzp; c += TZ_THREADS) qv[c] = (c < nz) ? p.q[(size_t)b * nz + c] : 0.0;
-    TZ_ROWS(k, r) h_[k] = p.h[(size_t)b * mi + r];
+    TZ_ROWS(k, r) TZ_SET_H(k, r, p.h[(size_t)b * mi + r]);
     if (t == 0) *flag = 0;
   }
   if (src != 2) { TZ_ROWS(k, r) l_[k] = 1.0; }
@@ -936,14 +951,14 @@ retry_solve:
     }
     // G x of the starting point: inside a launch gx_ still holds it (it followed x through the iterations of the previous
     // step); it is formed afresh every eighth step so that rounding does not accumulate along a trajectory
-    if (src != 2 || (step & 7) == 0 || retried || shifted) tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
+    if (src != 2 || (step & 7) == 0 || retried || shifted) { tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
     double viol = 0.0;
-    TZ_ROWS(k, r) { viol = fmax(viol, gx_[k] - h_[k]); sch = fmax(sch, fabs(h_[k])); }
+    TZ_ROWS(k, r) { const double hv = TZ_H(k, r); viol = fmax(viol, TZ_GX(k, r) - hv); sch = fmax(sch, fabs(hv)); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
-    tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red);      // also the scales of the stopping test
+    tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red, rpar);      // also the scales of the stopping test
     const double sig = fmax(p.warm_floor, p.warm_gain * viol);
     TZ_ROWS(k, r) {
-      s_[k] = fmax(h_[k] - gx_[k], sig);
+      s_[k] = fmax(TZ_H(k, r) - TZ_GX(k, r), sig);
       l_[k] = fmax(l_[k], sig);
     }
   }
@@ -952,7 +967,7 @@ retry_solve:
     // ---- cold start: (P + G'G + reg) x = -q + G'h, then shift the slacks into the cone
     tz_gram(p, Hq, Pq, vin, kl);
     __syncthreads();
-    TZ_ROWS(k, r) vin[r] = h_[k];
+    TZ_ROWS(k, r) vin[r] = TZ_H(k, r);
     __syncthreads();
     if (!wave0) tz_ell_gemvT_part(p, vin, pl);
     __syncthreads();
@@ -962,15 +977,16 @@ retry_solve:
     else okf = tz_cholesky(p, Hq, dinv, flag);
     if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, xv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
     tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
+    if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; }
   }
   if (!warm) {
     double rmin = 1e300;
     scq = 0.0; sch = 0.0;
-    TZ_ROWS(k, r) { rmin = fmin(rmin, h_[k] - gx_[k]); sch = fmax(sch, fabs(h_[k])); }
+    TZ_ROWS(k, r) { const double hv = TZ_H(k, r); rmin = fmin(rmin, hv - TZ_GX(k, r)); sch = fmax(sch, fabs(hv)); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
-    tz_block_reduce3<RED_MIN, RED_MAX, RED_MAX>(rmin, scq, sch, red);
+    tz_block_reduce3<RED_MIN, RED_MAX, RED_MAX>(rmin, scq, sch, red, rpar);
     const double shift = (rmin <= 1e-8) ? fmax(0.0, 1.0 - rmin) : 0.0;
-    TZ_ROWS(k, r) s_[k] = h_[k] - gx_[k] + shift;
+    TZ_ROWS(k, r) s_[k] = TZ_H(k, r) - TZ_GX(k, r) + shift;
   }
   }
   // scales of the stopping test: parked in LDS (two spare slots of the reduction buffer) instead of four registers for the whole solve
@@ -989,8 +1005,8 @@ retry_solve:
     // carried along at all: the right-hand sides below are written without it, and it is evaluated (exactly) only when rp and
     // mu already pass the test
     double nrp = 0, sl = 0, z0 = 0;
-    TZ_ROWS(k, r) { rp_[k] = gx_[k] + s_[k] - h_[k]; nrp = fmax(nrp, fabs(rp_[k])); sl += s_[k] * l_[k]; }
-    tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM>(nrp, sl, z0, red);
+    TZ_ROWS(k, r) { rp_[k] = TZ_GX(k, r) + s_[k] - TZ_H(k, r); nrp = fmax(nrp, fabs(rp_[k])); sl += s_[k] * l_[k]; }
+    tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM, 2>(nrp, sl, z0, red, rpar);
     const double mu = sl / mi;
     nrp /= red[13];
     if (!(mu == mu) || !(nrp == nrp) || mu > 1e200) { status = 2; break; }
@@ -998,7 +1014,7 @@ retry_solve:
       exact_rd();
       double e1 = 0, e2 = 0, e3 = 0;
       for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
-      tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(e1, e2, e3, red);
+      tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX, 1>(e1, e2, e3, red, rpar);
       const double nrd = e1 / red[12];
       TZ_STAMP(PH_GEMVT);
       if (!(nrd == nrd)) { status = 2; break; }
@@ -1063,12 +1079,19 @@ retry_solve:
       ds_[k] = ds; dl_[k] = dl;
       mp = fmax(mp, -ds * is_[k]);
       md = fmax(md, -dl * il_[k]);
+      z4 += (s_[k] + ds) * (l_[k] + dl);
     }
-    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(mp, md, z4, red);
+    // z4: complementarity after the affine step, summed for the full step in the same reduction as the step lengths: when the full
+    // step is feasible (the usual case from a warm start) that sum is the one wanted, otherwise it is formed again with ap, ad
+    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(mp, md, z4, red, rpar);
     const double ap = 1.0 / fmax(1.0, mp), ad = 1.0 / fmax(1.0, md);
-    double muaff = 0, z1 = 0, z2 = 0;
-    TZ_ROWS(k, r) muaff += (s_[k] + ap * ds_[k]) * (l_[k] + ad * dl_[k]);
-    tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(muaff, z1, z2, red);
+    double muaff = z4;
+    if (mp > 1.0 || md > 1.0) {
+      double z1 = 0, z2 = 0;
+      muaff = 0.0;
+      TZ_ROWS(k, r) muaff += (s_[k] + ap * ds_[k]) * (l_[k] + ad * dl_[k]);
+      tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM, 1>(muaff, z1, z2, red, rpar);
+    }
     muaff /= mi;
     const double sfr = (attempt == 0) ? p.step_frac : fmin(p.step_frac, 0.99);
     if (fmin(ap, ad) >= p.aff_thr && muaff <= p.aff_mu * mu) {
@@ -1076,7 +1099,7 @@ retry_solve:
       const double mmA = fmax(mp, md);
       const double alphaA = (mmA > sfr) ? sfr / mmA : 1.0;
       for (int c = t; c < nz; c += TZ_THREADS) xv[c] += alphaA * dxv[c];
-      TZ_ROWS(k, r) { s_[k] += alphaA * ds_[k]; l_[k] += alphaA * dl_[k]; gx_[k] += alphaA * g_[k]; }
+      TZ_ROWS(k, r) { s_[k] += alphaA * ds_[k]; l_[k] += alphaA * dl_[k]; TZ_ADD_GX(k, r, alphaA * g_[k]); }
       __syncthreads();
       continue;
     }
@@ -1109,11 +1132,11 @@ retry_solve:
       ms = fmax(ms, -ds * is_[k]);
       ml = fmax(ml, -dl * il_[k]);
     }
-    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(ms, ml, z3, red);
+    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM, 2>(ms, ml, z3, red, rpar);
     const double mm = fmax(ms, ml);
     const double alpha = (mm * 1.0 > sfr) ? sfr / mm : 1.0;      // min(1, sfr * min_i(-v_i/dv_i))
     for (int c = t; c < nz; c += TZ_THREADS) xv[c] += alpha * dxv[c];
-    TZ_ROWS(k, r) { s_[k] += alpha * ds_[k]; l_[k] += alpha * dl_[k]; gx_[k] += alpha * g_[k]; }
+    TZ_ROWS(k, r) { s_[k] += alpha * ds_[k]; l_[k] += alpha * dl_[k]; TZ_ADD_GX(k, r, alpha * g_[k]); }
     __syncthreads();
   }
   TZ_FRESH_T();
@@ -1157,7 +1180,7 @@ retry_solve:
     double acc = 0.0, z1 = 0.0, z2 = 0.0;
     if (want_cost) {
       for (int c = t; c < nz; c += TZ_THREADS) acc += xv[c] * (0.5 * (px_in_part ? part[c] : tz_gemvT_get(part, nzp, c)) + qv[c]);
-      tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM>(acc, z1, z2, red);
+      tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM, 1>(acc, z1, z2, red, rpar);
     }
     if (t == 0 && !want_cost) { if (F.plant.sticky && F.plant.sticky[b] == 0 && status != 0) F.plant.sticky[b] = status; }
     if (t == 0 && want_cost) {

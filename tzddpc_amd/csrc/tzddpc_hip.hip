@@ -524,7 +524,13 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (p->lds_bytes > 160 * 1024)
     TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
   p->maxr = (mi + TZ_THREADS - 1) / TZ_THREADS; p->ncg = (nzp + 63) / 64;
-  p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg, (int)((160 * 1024) / std::max<size_t>(p->lds_bytes, 1)));
+  const int wgs_per_cu = (int)((160 * 1024) / std::max<size_t>(p->lds_bytes, 1));
+  p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg, wgs_per_cu);
+  if (wgs_per_cu >= 4 || p->ncg == 1) {    // the 128-register variant parks h and G x of the rows in LDS
+    p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist, p->ntheta, p->ksplit ? 1 : 0, p->ntube, p->nell, 1) * sizeof(double);
+    if (p->lds_bytes > 160 * 1024)
+      TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
+  }
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
   if (const char* e = getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
   if (p->prof && !TZ_PROFILE) TZ_FAIL(TZ_ERR_INVALID, "TZ_PROF=1 needs the diagnostic build of the library (libtzddpc_hip_prof.so)");
