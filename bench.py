@@ -124,6 +124,11 @@ def main():
 
     ctl, A, Bm, zon = build_controller(local_rank, args.horizon)
     nat = ctl._native
+    # one HIP stream for the kernel, torch's copies and the collective: the exchange is ordered after the closed loop on the device,
+    # without a host round trip in between
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
+    nat.set_stream(side.cuda_stream)
     n, m = ctl.qp.n, ctl.qp.m
     Bl = args.batch
     total = Bl * world
@@ -165,17 +170,15 @@ def main():
     t0 = time.perf_counter()
     run(False, K)
     ta = time.perf_counter()
-    nat.sync()
-    tb = time.perf_counter()
     gathered = collect()                                                      # per-trajectory cost + final state only
-    tc = time.perf_counter()
+    tb = time.perf_counter()
     torch.cuda.synchronize()
-    td = time.perf_counter()
-    if os.environ.get("TZ_BENCH_DEBUG"):
-        print(f"[rank {rank}] call {1e3*(ta-t0):.3f} sync {1e3*(tb-ta):.3f} gather {1e3*(tc-tb):.3f} sync {1e3*(td-tc):.3f} ms", file=sys.stderr)
+    tc = time.perf_counter()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("TZ_BENCH_DEBUG"):
+        print(f"[rank {rank}] launch {1e3*(ta-t0):.3f} collect (issue) {1e3*(tb-ta):.3f} synchronize {1e3*(tc-tb):.3f} barrier {1e3*(elapsed-(tc-t0)):.3f} ms", file=sys.stderr)
     ipm_ms, ipm_n = nat.timing_get(1)
     prep_ms, _ = nat.timing_get(0); fin_ms, _ = nat.timing_get(2); plant_ms, _ = nat.timing_get(3)
     bad |= (status != 0).int()

@@ -45,6 +45,8 @@ struct IpmParams {
   const int* prev_status;   // warm start gate: status of the previous closed-loop step (may alias nothing else); null = cold
   int* status_copy;         // optional second destination of the status (library-owned copy for the next step)
   int max_iter; double tol, reg, step_frac;
+  double mu_floor, tol_loose, step_frac_retry;   // 1e-3 mu_tol, 1e3 tol, min(step_frac, 0.99): formed on the host (uniform f64 expressions
+                              // have no scalar ALU: the compiler hoists them out of the step loop into vector registers and spills them)
   double mu_tol;              // complementarity target (<= tol): the distance to the solution of a degenerate problem goes like sqrt(mu)
   int warm_steps;             // multi-step launches: step k+1 starts from the solution of step k
   int nell;                   // max(eg.VL, et.VL)
@@ -203,7 +205,9 @@ __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double*
 #pragma unroll
   for (int k = 0; k < MAXR; ++k) {
     double a = 0.0;
-    const int first = rseg[k] & 0xffff, cnt = rseg[k] >> 16;
+    int sg = rseg[k];
+    asm volatile("" : "+v"(sg));                     // launch-invariant per lane: keep the derived addresses out of the hoisted (and spilled) set
+    const int first = sg & 0xffff, cnt = sg >> 16;
     for (int j = 0; j < cnt; ++j) a += pl[first + j];
     out[k] = a;
   }
@@ -230,6 +234,7 @@ __device__ inline void tz_ell_gemvT_part(const IpmParams& p, const double* in, d
 }
 __device__ inline double tz_ell_colsum(const double* pl, int cseg) {
   double a = 0.0;
+  asm volatile("" : "+v"(cseg));                     // as in tz_ell_gemv
   const int first = cseg & 0xffff, cnt = cseg >> 16;
   for (int j = 0; j < cnt; ++j) a += pl[first + j];
   return a;
@@ -1010,7 +1015,7 @@ retry_solve:
     const double mu = sl / mi;
     nrp /= red[13];
     if (!(mu == mu) || !(nrp == nrp) || mu > 1e200) { status = 2; break; }
-    if ((nrp <= p.tol && mu <= p.mu_tol) || mu <= 1e-3 * p.mu_tol) {
+    if ((nrp <= p.tol && mu <= p.mu_tol) || mu <= p.mu_floor) {
       exact_rd();
       double e1 = 0, e2 = 0, e3 = 0;
       for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
@@ -1019,7 +1024,7 @@ retry_solve:
       TZ_STAMP(PH_GEMVT);
       if (!(nrd == nrd)) { status = 2; break; }
       if (nrd <= p.tol && nrp <= p.tol && mu <= p.mu_tol) { status = 0; px_in_part = true; break; }
-      if (mu <= 1e-3 * p.mu_tol) { status = (nrd <= 1e3 * p.tol && nrp <= 1e3 * p.tol) ? 0 : 3; px_in_part = true; break; }
+      if (mu <= p.mu_floor) { status = (nrd <= p.tol_loose && nrp <= p.tol_loose) ? 0 : 3; px_in_part = true; break; }
     }
     // Newton matrix.  is = 1/s, il = 1/lambda are the only two divisions per row and iteration.
     TZ_ROWS(k, r) { is_[k] = 1.0 / s_[k]; il_[k] = 1.0 / l_[k]; w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
@@ -1093,7 +1098,7 @@ retry_solve:
       tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM, 1>(muaff, z1, z2, red, rpar);
     }
     muaff /= mi;
-    const double sfr = (attempt == 0) ? p.step_frac : fmin(p.step_frac, 0.99);
+    const double sfr = (attempt == 0) ? p.step_frac : p.step_frac_retry;
     if (fmin(ap, ad) >= p.aff_thr && muaff <= p.aff_mu * mu) {
       // the Newton (predictor) step is already (almost) a full step and kills complementarity: take it, skip the corrector
       const double mmA = fmax(mp, md);

@@ -110,9 +110,13 @@ template <int W> ipm_fn_t ipm_pick_maxr(int maxr, int ncg) {
 }
 // wgs_per_cu: how many workgroups of this problem fit in one CU's LDS (the register budget is chosen to match)
 ipm_fn_t ipm_kernel_for(int maxr, int ncg, int wgs_per_cu) {
+#ifdef TZ_ONLY_SMALL      // development builds (assembly study, quick A/B of the bench problem): only the variant for mi <= 256, nz <= 64
+  return (maxr == 1 && ncg == 1) ? tz_ipm_kernel<1, 1, TZ_MINWAVES> : nullptr;
+#else
   if (wgs_per_cu >= 4) return ipm_pick_maxr<4>(maxr, ncg);
   if (wgs_per_cu >= 2) return ipm_pick_maxr<2>(maxr, ncg);
   return ipm_pick_maxr<1>(maxr, ncg);
+#endif
 }
 
 }  // namespace
@@ -238,6 +242,7 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
   ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
   ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac; ip.mu_tol = p->tol * p->mu_factor;
+  ip.mu_floor = 1e-3 * ip.mu_tol; ip.tol_loose = 1e3 * p->tol; ip.step_frac_retry = std::min(p->step_frac, 0.99);
   ip.prof = p->prof ? p->prof_buf.p : nullptr;
   ip.work = p->timing ? p->work_buf.p : nullptr;
   ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0; ip.chol1 = p->chol1 ? 1 : 0; ip.ntube = p->ntube;
@@ -295,7 +300,7 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
   {
     Timer tm(p, K_IPM);
     IpmParams ip = ipm_params(p, B, d_status, d_iters, warm, track_prev);
-    if (d_active) ip.mu_tol *= 1e-3;      // active-set readout (slack < multiplier) needs the complementarity products well below the slacks
+    if (d_active) { ip.mu_tol *= 1e-3; ip.mu_floor *= 1e-3; }     // active-set readout (slack < multiplier) needs the complementarity products well below the slacks
     hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, st, ip);
   }
   {
@@ -531,6 +536,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
     if (p->lds_bytes > 160 * 1024)
       TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
   }
+  if (!p->ipm_fn) TZ_FAIL(TZ_ERR_UNSUPPORTED, "this development build (TZ_ONLY_SMALL) carries only the mi <= 256, nz <= 64 kernel");
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
   if (const char* e = getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
   if (p->prof && !TZ_PROFILE) TZ_FAIL(TZ_ERR_INVALID, "TZ_PROF=1 needs the diagnostic build of the library (libtzddpc_hip_prof.so)");

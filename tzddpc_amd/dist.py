@@ -29,9 +29,12 @@ def gather_results(local, total: int):
     ws, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_range(total, ws, r) for r in range(ws)]
     maxb = max(hi - lo for lo, hi in sizes)
+    out = torch.empty((ws * maxb, local.shape[1]), dtype=local.dtype, device=local.device)
+    if total == ws * maxb:                     # equal shards: one collective straight from the caller's buffer, no padding, no trimming
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
     pad = torch.zeros((maxb, local.shape[1]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    out = torch.empty((ws * maxb, local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, pad)
     parts = [out[r * maxb: r * maxb + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
     return torch.cat(parts, dim=0)
