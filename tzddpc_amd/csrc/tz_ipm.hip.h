@@ -66,7 +66,7 @@ struct IpmParams {
   FuseParams F;               // F.on != 0: whole closed-loop step in this launch (q, h, prestatus above are then unused)
 };
 
-enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_CH_UPD = 8, PH_CH_DIAG = 9, PH_CH_PANEL = 10, PH_CH_BAR = 11, PH_PROLOGUE = 12, PH_EPILOGUE = 13, PH_GRAM_LOOP = 14, PH_GRAM_RED = 15, PH_GRAM_BAR = 16, PH_GRAM_RMW = 17, PH_COUNT = 18 };
+enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_CH_UPD = 8, PH_CH_DIAG = 9, PH_CH_PANEL = 10, PH_CH_BAR = 11, PH_PROLOGUE = 12, PH_EPILOGUE = 13, PH_GRAM_LOOP = 14, PH_GRAM_RED = 15, PH_GRAM_BAR = 16, PH_GRAM_RMW = 17, PH_TUBE = 18, PH_WARM = 19, PH_TOP = 20, PH_STEP = 21, PH_COUNT = 22 };
 
 __device__ inline int tz_qprefix(int I) {   // number of quads in tile rows < I (row I has (I>>2)+1 quads)
   int a = I >> 2, b = I & 3;
@@ -763,7 +763,7 @@ __device__ inline void tz_chol_solve_wave(const IpmParams& p, const double* Hq, 
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
 __host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit, int ntube, int nell, int park = 0) {
-  return (park ? 2 * (size_t)mip : 0) + (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 14 * (size_t)nzp + (size_t)(mip + 4) + 32 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 3 * TZ_NMAX + (size_t)ntube + (size_t)nell;
+  return (park ? 2 * (size_t)mip : 0) + (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 14 * (size_t)nzp + (size_t)(mip + 4) + 32 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 4 * TZ_NMAX + (size_t)ntube + (size_t)nell;
 }
 
 typedef __attribute__((address_space(4))) const IpmParams* TzKargPtr;
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   constexpr bool PROF = false;            // the diagnostic build (libtzddpc_hip_prof.so, -DTZ_PROFILE=1) carries the per-phase clocks
 #endif
   unsigned long long tprev = 0, tstart = 0;
-  unsigned long long acc_ph[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long acc_ph[PH_COUNT] = {};
 #define TZ_STAMP(ph) do { if (PROF) { unsigned long long _t = __builtin_amdgcn_s_memtime(); acc_ph[ph] += _t - tprev; tprev = _t; } } while (0)
   if (PROF) { tprev = __builtin_amdgcn_s_memtime(); tstart = tprev; }
   extern __shared__ double lds[];
@@ -810,8 +810,8 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   int* flag = (int*)(red + 32);
   int* kl = (int*)(red + 34);
   double* thl = red + 34 + (p.nklist + 1) / 2;      // theta of this trajectory (fused step only)
-  double* stl = thl + p.F.ntheta;                   // fused: closed-loop state [x | xbar | e] (3 TZ_NMAX doubles)
-  double* pl = stl + 3 * TZ_NMAX;                   // partial sums of the lane-ELL products (nell doubles)
+  double* stl = thl + p.F.ntheta;                   // fused: closed-loop state [x | xbar | e] (3 n doubles), disturbance of the step at 3 TZ_NMAX
+  double* pl = stl + 4 * TZ_NMAX;                   // partial sums of the lane-ELL products (nell doubles)
   double* tbl = pl + p.nell;                  // fused: C_K powers and the tube resolvent (copied once per launch)
   double* Pq = tbl + p.ntube;                       // ksplit: P + reg I in the quad layout of Hq (lower tiles)
   // 128-register variant: h and G x of the rows live in LDS (each thread touches only its own slots: no barrier) -- two
@@ -857,6 +857,8 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     for (int i = t; i < n; i += TZ_THREADS) ec[n * n + 2 * n * m + i] = F0.fin.r1[i];
     for (int i = t; i < n * nv; i += TZ_THREADS) ec[3 * n * n + 2 * n * m + n + i] = F0.fin.Gam[(size_t)n * nv + i];
     for (int i = t; i < nv; i += TZ_THREADS) ec[3 * n * n + 2 * n * m + n + n * nv + i] = F0.fin.Dz[i];
+    int* pwl = (int*)(ec + 3 * n * n + 2 * n * m + n + n * nv + nv);                // power[k] of the N steps (tube)
+    for (int i = t; i < F0.fin.N; i += TZ_THREADS) pwl[i] = F0.tube.power[i];
   }
   if (fused && t < F0.fin.n) {                    // closed-loop state [x | xbar | e] stays in LDS for all steps of this launch
     stl[t] = F0.plant.x[(size_t)b * F0.fin.n + t];
@@ -888,11 +890,22 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   asm volatile("" : "+s"(kp0));
   const FuseParams& F = ((const IpmParams*)kp0)->F;
   bool skip = false;                        // fused step: a parameter row is violated -> status 3, u = K e, nominal state from Phi
+  // disturbance of this step: needed only by the plant update at the very end, but a cold line (every step of every trajectory
+  // has its own) -- fetched now, parked in LDS at the end of the prologue
+  double wpre = 0.0;
+  if (fused && t < F.fin.n) wpre = F.plant.w[(size_t)b * F.plant.w_stride + (size_t)step * F.w_step + t];
   for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the cold start point
   if (fused) {
     if (t == 0) { flag[0] = 0; flag[1] = 0; }
-    tz_tube_block(F.tube, tbl, tbl + (F.tube.pmax + 1) * F.tube.n * F.tube.n, stl + F.fin.n, stl + 2 * F.fin.n, Hq, thl, t, TZ_THREADS);       // the factor storage is free until the first Gram
+    {                                                                                  // the factor storage is free until the first Gram
+      const int n = F.fin.n, m = F.fin.m, nv = F.fin.N * m;
+      const double* Tt = tbl + (F.tube.pmax + 1) * n * n;
+      const int* pwl = (const int*)(Tt + (F.tube.pmax > 0 ? F.tube.pmax : 1) * (n + m) * n + 3 * n * n + 2 * n * m + n + n * nv + nv);
+      if (n == 2 && m == 1) tz_tube_block<2, 1>(F.tube, tbl, Tt, pwl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS);
+      else tz_tube_block(F.tube, tbl, Tt, pwl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS);
+    }
     __syncthreads();
+    TZ_STAMP(PH_TUBE);
     for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? csr_row(F.qmap, c, thl) : 0.0; if (src != 2) xv[c] = 0.0; }
     int bad = 0;
     for (int r = t; r < F.npar; r += TZ_THREADS) {
@@ -907,6 +920,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     if (t == 0) *flag = 0;
   }
   if (src != 2) { TZ_ROWS(k, r) l_[k] = 1.0; }
+  if (fused && t < F.fin.n) stl[3 * TZ_NMAX + t] = wpre;
   __syncthreads();
   if (fused && flag[1] != 0) { skip = true; TZ_ROWS(k, r) { s_[k] = 1.0; l_[k] = 0.0; } for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0; }
   TZ_STAMP(PH_PROLOGUE);
@@ -999,10 +1013,11 @@ retry_solve:
   __syncthreads();
 
   status = skip ? 3 : (okf ? 1 : 2);
+  TZ_STAMP(PH_WARM);
   bool px_in_part = false;                  // `part` holds the partial sums of P x for the final x (left there by exact_rd)
   for (it = 0; it < p.max_iter && status == 1; ++it) {
     TZ_FRESH_T();
-    TZ_STAMP(PH_ELEM);
+    TZ_STAMP(PH_STEP);
     double w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR], is_[MAXR], il_[MAXR];      // scratch of this iteration only
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) { w_[k] = 0.0; rp_[k] = 0.0; ds_[k] = 0.0; dl_[k] = 0.0; g_[k] = 0.0; is_[k] = 1.0; il_[k] = 1.0; }
@@ -1029,7 +1044,7 @@ retry_solve:
     // Newton matrix.  is = 1/s, il = 1/lambda are the only two divisions per row and iteration.
     TZ_ROWS(k, r) { is_[k] = 1.0 / s_[k]; il_[k] = 1.0 / l_[k]; w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
     __syncthreads();
-    TZ_STAMP(PH_ELEM);
+    TZ_STAMP(PH_TOP);
     tz_gram(p, Hq, Pq, vin, kl, (PROF && t == 0) ? acc_ph : nullptr);
     __syncthreads();
     TZ_STAMP(PH_FORM);
@@ -1187,7 +1202,7 @@ retry_solve:
       for (int c = t; c < nz; c += TZ_THREADS) acc += xv[c] * (0.5 * (px_in_part ? part[c] : tz_gemvT_get(part, nzp, c)) + qv[c]);
       tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM, 1>(acc, z1, z2, red, rpar);
     }
-    if (t == 0 && !want_cost) { if (F.plant.sticky && F.plant.sticky[b] == 0 && status != 0) F.plant.sticky[b] = status; }
+    if (t == 0 && !want_cost) { if (status != 0 && F.plant.sticky && F.plant.sticky[b] == 0) F.plant.sticky[b] = status; }
     if (t == 0 && want_cost) {
       double r = F.fin.r0;
       for (int i = 0; i < n; ++i) {
@@ -1195,7 +1210,7 @@ retry_solve:
         for (int j = 0; j < n; ++j) r += x0[i] * cR2[i * n + j] * x0[j];
       }
       F.fin.cost[(size_t)b * F.fin.cost_stride + (size_t)step * F.cost_step] = (status == 0 || status == 1) ? acc / F.fin.cost_scale + r : INFINITY;
-      if (F.plant.sticky && F.plant.sticky[b] == 0 && status != 0) F.plant.sticky[b] = status;
+      if (status != 0 && F.plant.sticky && F.plant.sticky[b] == 0) F.plant.sticky[b] = status;
     }
     if (F.fin.v) for (int c = t; c < nv; c += TZ_THREADS) F.fin.v[(size_t)b * nv + c] = dxv[c];
     if (F.fin.xbar) {                                    // whole predicted nominal trajectory (single-step launches)
@@ -1207,18 +1222,20 @@ retry_solve:
         F.fin.xbar[(size_t)b * (N + 1) * n + r] = a;
       }
     }
-    if (t < n) {                                         // xbar[1], the next nominal state
-      double a = 0.0;
-      for (int j = 0; j < n; ++j) a += cPhi[t * n + j] * x0[j];
-      for (int c = 0; c < nv; ++c) a += cGam[t * nv + c] * dxv[c];
-      tmpz[t] = a;
+    if (wave0) {                                         // xbar[1], the next nominal state: one wave, the sums folded across its lanes
+      for (int i = 0; i < n; ++i) {
+        double a = (t < n) ? cPhi[i * n + t] * x0[t] : 0.0;
+        for (int c = t; c < nv; c += 64) a += cGam[i * nv + c] * dxv[c];
+        a = tz_wave_reduce<RED_SUM>(a);
+        if (t == i) tmpz[i] = a;
+      }
     }
     __syncthreads();
     if (t < 64) {
       const PlantParams& Q = F.plant;
       double xn = 0.0, xb = 0.0;
       if (t < n) {
-        xn = Q.w[(size_t)b * Q.w_stride + (size_t)step * F.w_step + t];
+        xn = stl[3 * TZ_NMAX + t];                          // w of this step (fetched in the prologue)
         for (int j = 0; j < n; ++j) xn += cA[t * n + j] * stl[j];
         for (int j = 0; j < m; ++j) {
           double u = dxv[j];
@@ -1238,6 +1255,7 @@ retry_solve:
       }
     }
     __syncthreads();                          // the next step's tube pass reads the state
+    TZ_STAMP(PH_EPILOGUE);
   }
   }   // steps
   if (PROF && t == 0) {

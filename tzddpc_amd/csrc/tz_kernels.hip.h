@@ -62,8 +62,11 @@ __device__ inline double tz_quad_xor(double v) {                       // DPP qu
 }
 // All nt threads of the workgroup (tid) work on trajectory b.  aL: pmax * n doubles of LDS scratch; th: ntheta doubles (LDS or
 // global).  Contains one workgroup barrier; the caller adds another before th is read by other threads.
-__device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, const double* Ttab, const double* xbar0, const double* e0, double* aL, double* th, int tid, int nt) {
-  const int n = p.n, m = p.m, hs = 2 * n + m;
+// NC, MC: dim_x, dim_u known at compile time (0: taken from p) -- the index divisions become shifts / multiplies and the dot
+// products unroll; power: p.power or a copy of it in LDS.
+template <int NC = 0, int MC = 0>
+__device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, const double* Ttab, const int* power, const double* xbar0, const double* e0, double* aL, double* th, int tid, int nt) {
+  const int n = NC ? NC : p.n, m = MC ? MC : p.m, hs = 2 * n + m;
   for (int e = tid; e < p.pmax * n; e += nt) {
     const double* M = CKpow + (size_t)e * n;              // row i of C_K^l with e = l n + i
     double a = 0.0;
@@ -74,7 +77,7 @@ __device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, c
   __syncthreads();
   for (int e = tid; e < p.N * n; e += nt) {                      // centres c_k = C_K^power[k] e0
     const int k = e / n, i = e - k * n;
-    const double* M = CKpow + ((size_t)p.power[k] * n + i) * n;
+    const double* M = CKpow + ((size_t)power[k] * n + i) * n;
     double a = 0.0;
     for (int j = 0; j < n; ++j) a += M[j] * e0[j];
     th[2 * n + k * hs + i] = a;
@@ -82,7 +85,7 @@ __device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, c
   // radii: four lanes per entry (history index l = sub, sub + 4, ...), folded with two quad permutes
   const int sub = tid & 3;
   for (int q = tid >> 2; q < p.N * (n + m); q += nt >> 2) {
-    const int k = q / (n + m), comp = q - k * (n + m), pw = p.power[k];
+    const int k = q / (n + m), comp = q - k * (n + m), pw = power[k];
     double a = 0.0;
     for (int l = sub; l < pw; l += 4) {
       const double* T = Ttab + ((size_t)(pw - 1 - l) * (n + m) + comp) * n;
@@ -98,7 +101,7 @@ __device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, c
 __global__ __launch_bounds__(64) void tz_tube_kernel(TubeParams p) {
   __shared__ double aL[TZ_PMAX * TZ_NMAX];
   const int b = blockIdx.x;
-  tz_tube_block(p, p.CKpow, p.T, p.xbar0 + (size_t)b * p.n, p.e0 + (size_t)b * p.n, aL, p.theta + (size_t)b * p.ntheta, threadIdx.x, 64);
+  tz_tube_block(p, p.CKpow, p.T, p.power, p.xbar0 + (size_t)b * p.n, p.e0 + (size_t)b * p.n, aL, p.theta + (size_t)b * p.ntheta, threadIdx.x, 64);
   if (threadIdx.x == 0) p.prestatus[b] = 0;
 }
 

@@ -520,7 +520,8 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
 
   p->ksplit = (p->Tz <= TZ_KS_TZ);
   p->ntube = (d->pmax + 1) * d->n * d->n + std::max(d->pmax, 1) * (d->n + d->m) * d->n         // tube tables
-             + 3 * d->n * d->n + 2 * d->n * d->m + d->n + d->n * d->N * d->m + d->N * d->m;       // recovery / plant constants
+             + 3 * d->n * d->n + 2 * d->n * d->m + d->n + d->n * d->N * d->m + d->N * d->m        // recovery / plant constants
+             + (d->N + 1) / 2;                                                                    // power[k] (ints)
   p->chol1 = (p->Tz <= 16);
   if (const char* e = getenv("TZ_CHOL1")) { if (e[0] == '0') p->chol1 = false; }
   if (const char* e = getenv("TZ_KSPLIT")) { if (e[0] == '0') p->ksplit = false; }
