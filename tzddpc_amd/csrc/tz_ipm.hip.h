@@ -583,7 +583,20 @@ __device__ inline void tz_wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ inline void tz_cholesky_wave(const IpmParams& p, double* Hq, double* dinv, int* flag) {
+// Bounded wait of one wave for a counter in LDS that other waves of the workgroup advance (release stores / adds): true when
+// *f >= target was seen.  The bound is a safety net (the producers never wait for this wave): ~1e6 polls.
+__device__ inline bool tz_spin_until(const int* f, int target) {
+  for (int guard = 0; guard < (1 << 20); ++guard) {
+    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (v >= target) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+
+// prog (LDS, may be null): number of finished tile columns, published after each one -- column pp of L and inv(L_pp,pp) are final
+// then, which is all the forward substitution trailing on another wave (tz_fwd_trailing) needs for its step pp.
+__device__ inline void tz_cholesky_wave(const IpmParams& p, double* Hq, double* dinv, int* flag, int* prog = nullptr) {
   const int Tz = p.Tz;
   const int lane = tz_tid() & 63;
   const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
@@ -623,6 +636,7 @@ __device__ inline void tz_cholesky_wave(const IpmParams& p, double* Hq, double* 
     }
     tz_factor_col(Tz, Hq, dinv, flag, pp, lane, 64);
     tz_wave_sync();
+    if (prog && lane == 0) __hip_atomic_store(prog, pp + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
 
@@ -712,7 +726,8 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
 // travels by v_readlane instead of an LDS publish + wave sync + read -- per tile step the dependent chain is four DPP quad
 // broadcasts, the 4x4 inverse-diagonal product, four readlanes and one fused update; the L / M entries of the next step are
 // independent LDS reads.  Called by all threads (waves 1-3 fall through); the caller's barrier publishes out.
-__device__ inline void tz_chol_solve_wave(const IpmParams& p, const double* Hq, const double* dinv, const double* rhs, double* out) {
+// bwd_only: rhs already holds y = inv(L) r (left there by tz_fwd_trailing).
+__device__ inline void tz_chol_solve_wave(const IpmParams& p, const double* Hq, const double* dinv, const double* rhs, double* out, bool bwd_only = false) {
   const int tt = tz_tid();
   if (tt >= 64) return;
   const int Tz = p.Tz, nzp = p.nzp;
@@ -735,12 +750,14 @@ __device__ inline void tz_chol_solve_wave(const IpmParams& p, const double* Hq, 
     const double y0 = tz_readlane(yc, 4 * I), y1 = tz_readlane(yc, 4 * I + 1), y2 = tz_readlane(yc, 4 * I + 2), y3 = tz_readlane(yc, 4 * I + 3);
     rv = (tq == I) ? yc : rv - ((ll[0] * y0 + ll[1] * y1) + (ll[2] * y2 + ll[3] * y3));
   };
+  if (!bwd_only) {
   fwd_load(0, mA, lA);
   for (int I = 0; I < Tz; I += 2) {                                    // ---- forward: L y = rhs
     fwd_load(I + 1, mB, lB);
     fwd_step(I, mA, lA);
     fwd_load(I + 2, mA, lA);
     if (I + 1 < Tz) fwd_step(I + 1, mB, lB);
+  }
   }
   const int colbase = (t >> 4) * TZ_QSTR + 4 * ((t >> 2) & 3) + (t & 3);        // + qprefix(I)*QSTR + QROW k: L(4I + k, t)
   auto bwd_load = [&](int I, double (&mm)[4], double (&ll)[4]) {
@@ -759,6 +776,31 @@ __device__ inline void tz_chol_solve_wave(const IpmParams& p, const double* Hq, 
     if (I - 1 >= 0) fwd_step(I - 1, mB, lB);
   }
   if (t < nzp) out[t] = rv;
+}
+
+// Forward substitution L y = r by ONE wave (any: lane = row) while another wave is still factoring: step I starts when the
+// factorisation has published column I (prog > I).  rv: this lane's entry of r; y goes to yout (LDS, nzp doubles).  Returns
+// false if the wait ran into its bound (never seen; the caller then fails the solve).
+__device__ inline bool tz_fwd_trailing(const IpmParams& p, const double* Hq, const double* dinv, double rv, const int* prog, double* yout) {
+  const int Tz = p.Tz, nzp = p.nzp;
+  const int t = tz_tid() & 63, jq = t & 3, tq = t >> 2;
+  const int rowbase = tz_qprefix(tq < Tz ? tq : 0) * TZ_QSTR + TZ_QROW * jq;
+  bool ok = true;
+  for (int I = 0; I < Tz; ++I) {
+    if (!tz_spin_until(prog, I + 1)) { ok = false; break; }
+    const double* m = dinv + I * 16 + 4 * jq;                          // row jq of M_I = inv(L_II)
+    const int base = rowbase + (I >> 2) * TZ_QSTR + 4 * (I & 3);
+    const bool below = tq > I && tq < Tz;
+    double mm[4], ll[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mm[k] = m[k]; ll[k] = below ? Hq[base + k] : 0.0; }
+    const double a0 = tz_quad_bcast<0>(rv), a1 = tz_quad_bcast<1>(rv), a2 = tz_quad_bcast<2>(rv), a3 = tz_quad_bcast<3>(rv);
+    const double yc = (mm[0] * a0 + mm[1] * a1) + (mm[2] * a2 + mm[3] * a3);
+    const double y0 = tz_readlane(yc, 4 * I), y1 = tz_readlane(yc, 4 * I + 1), y2 = tz_readlane(yc, 4 * I + 2), y3 = tz_readlane(yc, 4 * I + 3);
+    rv = (tq == I) ? yc : rv - ((ll[0] * y0 + ll[1] * y1) + (ll[2] * y2 + ll[3] * y3));
+  }
+  if (t < nzp) yout[t] = rv;
+  return ok;
 }
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
@@ -786,6 +828,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   int t = threadIdx.x;                     // re-laundered at phase boundaries (TZ_FRESH_T, see tz_tid)
 #define TZ_FRESH_T() asm volatile("" : "+v"(t))
   const bool wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+  const bool wave1 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1;
   const int nz = p.nz, mi = p.mi, nzp = p.nzp, mip = p.mip;
   const FuseParams& F0 = p.F;
   const bool fused = F0.on != 0;          // closed-loop step in one launch: tube + parameter maps before, recovery + plant after
@@ -830,7 +873,10 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   int rseg_[MAXR];                                   // lanes of the G x product that carry this thread's rows
 #pragma unroll
   for (int k = 0; k < MAXR; ++k) { const int r = t + TZ_THREADS * k; rseg_[k] = (r < mi) ? p.eg.seg[r] : 0; }
-  const int cseg = (t < nz) ? p.et.seg[t] : 0;       // lanes of the G'v product that carry column t
+  // lanes of the G'v product that carry column t; for nz <= 64 wave 1 holds a second copy (column t - 64): it assembles the
+  // predictor's right-hand side while wave 0 factors
+  const int ccol = (nzp <= 64 && t >= 64) ? (t < 128 ? t - 64 : nz) : t;
+  const int cseg = (ccol < nz) ? p.et.seg[ccol] : 0;
 
   // ---- once per launch: constants of the problem into LDS, closed-loop state of the trajectory -------------------------
   if (p.ksplit) {
@@ -1052,22 +1098,35 @@ retry_solve:
     // ---- predictor (rc = s*lam):  H dx = -(P x + q) - G'(w rp).  The factorisation of H and the two products on the right
     // are independent: with chol1 wave 0 factors while waves 1-3 form the right-hand side.
     TZ_ROWS(k, r) vin[r] = w_[k] * rp_[k];
+    if (t == 0) { flag[2] = 0; flag[3] = 0; }        // columns factored / waves done with the right-hand side
     __syncthreads();
     bool okc;
+    bool have_y = false;                                // tmpz holds y = inv(L) r1 (forward substitution done while factoring)
     if (p.chol1) {
-      if (wave0) tz_cholesky_wave(p, Hq, dinv, flag);
+      if (wave0) tz_cholesky_wave(p, Hq, dinv, flag, flag + 2);
       else {
         tz_ell_gemvT_part(p, vin, pl);
         tz_gemvT_partial<NCG, 1, 3>(p.P, p.nP, nzp, xv, part2);
+        // the three waves meet on a counter (wave 0 is busy factoring); wave 1 then assembles the right-hand side and runs the
+        // forward substitution one tile column behind the factorisation
+        tz_wave_sync();
+        if ((tz_tid() & 63) == 0) __hip_atomic_fetch_add(flag + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wave1) {
+          bool ok1 = tz_spin_until(flag + 3, 3);
+          const int c = tz_tid() & 63;
+          double rv = 0.0;
+          if (c < nzp) {
+            const double pxq = (c < nz) ? tz_gemvT_get3(part2, nzp, c) + qv[c] : 0.0;
+            rdv[c] = pxq;                                                 // P x + q, used again by the corrector
+            rv = (c < nz) ? -pxq - tz_ell_colsum(pl, cseg) : 0.0;
+          }
+          ok1 = tz_fwd_trailing(p, Hq, dinv, rv, flag + 2, tmpz) && ok1;
+          if (!ok1 && c == 0) flag[0] = 3;
+        }
       }
       __syncthreads();
       okc = (*flag == 0);
-      for (int c = t; c < nzp; c += TZ_THREADS) {
-        const double pxq = (c < nz) ? tz_gemvT_get3(part2, nzp, c) + qv[c] : 0.0;
-        rdv[c] = pxq;                                                   // P x + q, used again by the corrector
-        r1v[c] = (c < nz) ? -pxq - tz_ell_colsum(pl, cseg) : 0.0;
-      }
-      __syncthreads();
+      have_y = true;
       TZ_STAMP(PH_CHOL);
     } else {
       if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part2);
@@ -1085,7 +1144,7 @@ retry_solve:
     }
     if (!okc) { status = 2; break; }
     TZ_FRESH_T();
-    if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, dxv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
+    if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, have_y ? tmpz : r1v, dxv, have_y); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
     tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
