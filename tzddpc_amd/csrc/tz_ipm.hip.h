@@ -45,6 +45,7 @@ struct IpmParams {
   const int* prev_status;   // warm start gate: status of the previous closed-loop step (may alias nothing else); null = cold
   int* status_copy;         // optional second destination of the status (library-owned copy for the next step)
   int max_iter; double tol, reg, step_frac;
+  double inv_mi;              // 1 / mi
   double mu_floor, tol_loose, step_frac_retry;   // 1e-3 mu_tol, 1e3 tol, min(step_frac, 0.99): formed on the host (uniform f64 expressions
                               // have no scalar ALU: the compiler hoists them out of the step loop into vector registers and spills them)
   double mu_tol;              // complementarity target (<= tol): the distance to the solution of a degenerate problem goes like sqrt(mu)
@@ -459,6 +460,15 @@ __device__ inline void tz_sqrt_rsqrt(double d, double& sq, double& rs) {
   const double e2 = __builtin_fma(-g, inv, 1.0);
   inv = __builtin_fma(e2, inv, inv);
   sq = g; rs = inv;
+}
+
+// 1/x from v_rcp_f64 (~2^-26) and two Newton steps: five instructions instead of the ~14 of the IEEE division sequence (the kernel
+// is issue-bound); to an ulp, for the positive normal x it is used on.
+__device__ inline double tz_recip(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  return y;
 }
 
 template <int JJ>
@@ -1073,22 +1083,22 @@ retry_solve:
     double nrp = 0, sl = 0, z0 = 0;
     TZ_ROWS(k, r) { rp_[k] = TZ_GX(k, r) + s_[k] - TZ_H(k, r); nrp = fmax(nrp, fabs(rp_[k])); sl += s_[k] * l_[k]; }
     tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM, 2>(nrp, sl, z0, red, rpar);
-    const double mu = sl / mi;
-    nrp /= red[13];
+    const double mu = sl * p.inv_mi;
+    nrp *= tz_recip(red[13]);
     if (!(mu == mu) || !(nrp == nrp) || mu > 1e200) { status = 2; break; }
     if ((nrp <= p.tol && mu <= p.mu_tol) || mu <= p.mu_floor) {
       exact_rd();
       double e1 = 0, e2 = 0, e3 = 0;
       for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
       tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX, 1>(e1, e2, e3, red, rpar);
-      const double nrd = e1 / red[12];
+      const double nrd = e1 * tz_recip(red[12]);
       TZ_STAMP(PH_GEMVT);
       if (!(nrd == nrd)) { status = 2; break; }
       if (nrd <= p.tol && nrp <= p.tol && mu <= p.mu_tol) { status = 0; px_in_part = true; break; }
       if (mu <= p.mu_floor) { status = (nrd <= p.tol_loose && nrp <= p.tol_loose) ? 0 : 3; px_in_part = true; break; }
     }
     // Newton matrix.  is = 1/s, il = 1/lambda are the only two divisions per row and iteration.
-    TZ_ROWS(k, r) { is_[k] = 1.0 / s_[k]; il_[k] = 1.0 / l_[k]; w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
+    TZ_ROWS(k, r) { is_[k] = tz_recip(s_[k]); il_[k] = tz_recip(l_[k]); w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
     __syncthreads();
     TZ_STAMP(PH_TOP);
     tz_gram(p, Hq, Pq, vin, kl, (PROF && t == 0) ? acc_ph : nullptr);
@@ -1163,7 +1173,7 @@ retry_solve:
     // z4: complementarity after the affine step, summed for the full step in the same reduction as the step lengths: when the full
     // step is feasible (the usual case from a warm start) that sum is the one wanted, otherwise it is formed again with ap, ad
     tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(mp, md, z4, red, rpar);
-    const double ap = 1.0 / fmax(1.0, mp), ad = 1.0 / fmax(1.0, md);
+    const double ap = tz_recip(fmax(1.0, mp)), ad = tz_recip(fmax(1.0, md));
     double muaff = z4;
     if (mp > 1.0 || md > 1.0) {
       double z1 = 0, z2 = 0;
@@ -1171,18 +1181,18 @@ retry_solve:
       TZ_ROWS(k, r) muaff += (s_[k] + ap * ds_[k]) * (l_[k] + ad * dl_[k]);
       tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM, 1>(muaff, z1, z2, red, rpar);
     }
-    muaff /= mi;
+    muaff *= p.inv_mi;
     const double sfr = (attempt == 0) ? p.step_frac : p.step_frac_retry;
     if (fmin(ap, ad) >= p.aff_thr && muaff <= p.aff_mu * mu) {
       // the Newton (predictor) step is already (almost) a full step and kills complementarity: take it, skip the corrector
       const double mmA = fmax(mp, md);
-      const double alphaA = (mmA > sfr) ? sfr / mmA : 1.0;
+      const double alphaA = (mmA > sfr) ? sfr * tz_recip(mmA) : 1.0;
       for (int c = t; c < nz; c += TZ_THREADS) xv[c] += alphaA * dxv[c];
       TZ_ROWS(k, r) { s_[k] += alphaA * ds_[k]; l_[k] += alphaA * dl_[k]; TZ_ADD_GX(k, r, alphaA * g_[k]); }
       __syncthreads();
       continue;
     }
-    double sigma = muaff / mu; sigma = sigma * sigma * sigma;
+    double sigma = muaff * tz_recip(mu); sigma = sigma * sigma * sigma;
     TZ_FRESH_T();
     // ---- corrector (rc = s*lam + dsa*dla - sigma mu):  H dx = -(P x + q) - G'(lam + (lam rp - rc) / s) -------------------
     TZ_ROWS(k, r) {
@@ -1213,7 +1223,7 @@ retry_solve:
     }
     tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM, 2>(ms, ml, z3, red, rpar);
     const double mm = fmax(ms, ml);
-    const double alpha = (mm * 1.0 > sfr) ? sfr / mm : 1.0;      // min(1, sfr * min_i(-v_i/dv_i))
+    const double alpha = (mm * 1.0 > sfr) ? sfr * tz_recip(mm) : 1.0;      // min(1, sfr * min_i(-v_i/dv_i))
     for (int c = t; c < nz; c += TZ_THREADS) xv[c] += alpha * dxv[c];
     TZ_ROWS(k, r) { s_[k] += alpha * ds_[k]; l_[k] += alpha * dl_[k]; TZ_ADD_GX(k, r, alpha * g_[k]); }
     __syncthreads();

@@ -242,7 +242,7 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
   ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
   ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac; ip.mu_tol = p->tol * p->mu_factor;
-  ip.mu_floor = 1e-3 * ip.mu_tol; ip.tol_loose = 1e3 * p->tol; ip.step_frac_retry = std::min(p->step_frac, 0.99);
+  ip.inv_mi = 1.0 / p->mi; ip.mu_floor = 1e-3 * ip.mu_tol; ip.tol_loose = 1e3 * p->tol; ip.step_frac_retry = std::min(p->step_frac, 0.99);
   ip.prof = p->prof ? p->prof_buf.p : nullptr;
   ip.work = p->timing ? p->work_buf.p : nullptr;
   ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0; ip.chol1 = p->chol1 ? 1 : 0; ip.ntube = p->ntube;
