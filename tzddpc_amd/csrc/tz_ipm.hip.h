@@ -107,14 +107,26 @@ __device__ inline double tz_op(double a, double b) { return (OP == RED_SUM) ? a 
 
 // Reduction over the 64 lanes of a wave, result in every lane.  Cross-lane moves by DPP (quad permutes, row rotations) and four
 // v_readlane for the rows of 16 -- no ds_bpermute round trips through the LDS crossbar.  Fixed combination order.
+// DPP move that only writes the rows of 16 lanes selected by ROWMASK (the others keep `old`)
+template <int CTRL, int ROWMASK>
+__device__ inline double tz_dpp_mov_rows(double old, double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v), o = __builtin_bit_cast(unsigned long long, old);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)u, CTRL, ROWMASK, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(u >> 32), CTRL, ROWMASK, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 template <int OP>
 __device__ inline double tz_wave_reduce(double v) {
   v = tz_op<OP>(v, tz_dpp_mov<0xB1>(v));             // quad_perm [1,0,3,2]
   v = tz_op<OP>(v, tz_dpp_mov<0x4E>(v));             // quad_perm [2,3,0,1]
   v = tz_op<OP>(v, tz_dpp_mov<0x124>(v));            // row_ror:4
   v = tz_op<OP>(v, tz_dpp_mov<0x128>(v));            // row_ror:8  -> every lane holds the result of its row of 16
-  const double r0 = tz_readlane(v, 0), r1 = tz_readlane(v, 16), r2 = tz_readlane(v, 32), r3 = tz_readlane(v, 48);
-  return tz_op<OP>(tz_op<OP>(r0, r1), tz_op<OP>(r2, r3));
+  // rows combined by the two row broadcasts (lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows 2, 3): lane 63 ends
+  // with the result of the wave, which leaves through two v_readlane -- fewer instructions than reading the four rows out
+  const double idn = (OP == RED_SUM) ? 0.0 : v;      // what the rows that receive nothing combine with
+  v = tz_op<OP>(v, tz_dpp_mov_rows<0x142, 0xA>(idn, v));        // row_bcast:15
+  v = tz_op<OP>(v, tz_dpp_mov_rows<0x143, 0xC>((OP == RED_SUM) ? 0.0 : v, v));   // row_bcast:31
+  return tz_readlane(v, 63);
 }
 
 // up to three simultaneous block reductions (ops fixed at compile time; the first NV of a, b, c take part); result broadcast to
