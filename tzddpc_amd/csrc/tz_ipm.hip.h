@@ -948,15 +948,17 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   // start point of this step: 0 cold, 1 the (x, lambda) stored by an earlier launch, 2 the (x, lambda) of the previous step (still
   // in LDS / registers)
   TZ_FRESH_T();
-  int src = 0;
-  if (step == 0) src = (p.warm != 0 && p.prev_status != nullptr && p.prev_status[b] == 0) ? 1 : 0;
-  else src = (p.warm_steps != 0 && status == 0) ? 2 : 0;
   // The fused-step arguments are needed only before and after the interior point: re-read them from the kernel argument
   // segment here and in the epilogue (opaque pointer: the loads cannot be hoisted out of the step loop, so the ~120 scalar
-  // registers they would pin are free during the solve).
+  // registers they would pin are free during the solve).  The same goes for the other arguments that only the start and the
+  // end of a step touch (stored solution, shift maps, warm-start switches): `pk` here, `pe` at the end, `pi` for the tolerances.
   TzKargPtr kp0 = (TzKargPtr)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(kp0));
   const FuseParams& F = ((const IpmParams*)kp0)->F;
+  const IpmParams& pk = *(const IpmParams*)kp0;
+  int src = 0;
+  if (step == 0) src = (pk.warm != 0 && pk.prev_status != nullptr && pk.prev_status[b] == 0) ? 1 : 0;
+  else src = (pk.warm_steps != 0 && status == 0) ? 2 : 0;
   bool skip = false;                        // fused step: a parameter row is violated -> status 3, u = K e, nominal state from Phi
   // disturbance of this step: needed only by the plant update at the very end, but a cold line (every step of every trajectory
   // has its own) -- fetched now, parked in LDS at the end of the prologue
@@ -983,8 +985,8 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     if (bad) flag[1] = 1;
     TZ_ROWS(k, r) TZ_SET_H(k, r, csr_row(F.hmap, r, thl));
   } else {
-    for (int c = t; c < nzp; c += TZ_THREADS) qv[c] = (c < nz) ? p.q[(size_t)b * nz + c] : 0.0;
-    TZ_ROWS(k, r) TZ_SET_H(k, r, p.h[(size_t)b * mi + r]);
+    for (int c = t; c < nzp; c += TZ_THREADS) qv[c] = (c < nz) ? pk.q[(size_t)b * nz + c] : 0.0;
+    TZ_ROWS(k, r) TZ_SET_H(k, r, pk.h[(size_t)b * mi + r]);
     if (t == 0) *flag = 0;
   }
   if (src != 2) { TZ_ROWS(k, r) l_[k] = 1.0; }
@@ -1018,23 +1020,23 @@ retry_solve:
     // by at least the amount the old point violates the new rows; a point that is too far outside starts cold instead
     // the previous solution, optionally moved one step along the horizon (v_k <- v_{k+1} ...: better in a transient, a matter of
     // the problem otherwise -- tz_problem_set_warm_shift)
-    const int prev_it = (step == 0) ? p.iters[b] : it;
-    const bool shifted = p.shift_policy == 1 || (p.shift_policy >= 2 && (prev_it >= p.shift_policy || (was_shifted != 0 && prev_it <= 1)));
+    const int prev_it = (step == 0) ? pk.iters[b] : it;
+    const bool shifted = pk.shift_policy == 1 || (pk.shift_policy >= 2 && (prev_it >= pk.shift_policy || (was_shifted != 0 && prev_it <= 1)));
     was_shifted = shifted ? 1 : 0;
     if (src == 1) {
       if (shifted) {
-        for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + p.sx[c]] * p.sxs[c];
-        TZ_ROWS(k, r) l_[k] = p.lam[(size_t)b * mi + p.sr[r]] * p.sls[r];
+        for (int c = t; c < nz; c += TZ_THREADS) xv[c] = pk.x[(size_t)b * nz + pk.sx[c]] * pk.sxs[c];
+        TZ_ROWS(k, r) l_[k] = pk.lam[(size_t)b * mi + pk.sr[r]] * pk.sls[r];
       } else {
-        for (int c = t; c < nz; c += TZ_THREADS) xv[c] = p.x[(size_t)b * nz + c];
-        TZ_ROWS(k, r) l_[k] = p.lam[(size_t)b * mi + r];
+        for (int c = t; c < nz; c += TZ_THREADS) xv[c] = pk.x[(size_t)b * nz + c];
+        TZ_ROWS(k, r) l_[k] = pk.lam[(size_t)b * mi + r];
       }
     } else if (shifted) {                                   // src == 2: x in LDS, lambda in registers of the row owners
-      for (int c = t; c < nz; c += TZ_THREADS) tmpz[c] = xv[p.sx[c]] * p.sxs[c];
+      for (int c = t; c < nz; c += TZ_THREADS) tmpz[c] = xv[pk.sx[c]] * pk.sxs[c];
       TZ_ROWS(k, r) vin[r] = l_[k];
       __syncthreads();
       for (int c = t; c < nz; c += TZ_THREADS) xv[c] = tmpz[c];
-      TZ_ROWS(k, r) l_[k] = vin[p.sr[r]] * p.sls[r];
+      TZ_ROWS(k, r) l_[k] = vin[pk.sr[r]] * pk.sls[r];
     }
     // G x of the starting point: inside a launch gx_ still holds it (it followed x through the iterations of the previous
     // step); it is formed afresh every eighth step so that rounding does not accumulate along a trajectory
@@ -1043,7 +1045,7 @@ retry_solve:
     TZ_ROWS(k, r) { const double hv = TZ_H(k, r); viol = fmax(viol, TZ_GX(k, r) - hv); sch = fmax(sch, fabs(hv)); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
     tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red, rpar);      // also the scales of the stopping test
-    const double sig = fmax(p.warm_floor, p.warm_gain * viol);
+    const double sig = fmax(pk.warm_floor, pk.warm_gain * viol);
     TZ_ROWS(k, r) {
       s_[k] = fmax(TZ_H(k, r) - TZ_GX(k, r), sig);
       l_[k] = fmax(l_[k], sig);
@@ -1083,8 +1085,13 @@ retry_solve:
   status = skip ? 3 : (okf ? 1 : 2);
   TZ_STAMP(PH_WARM);
   bool px_in_part = false;                  // `part` holds the partial sums of P x for the final x (left there by exact_rd)
-  for (it = 0; it < p.max_iter && status == 1; ++it) {
+  for (it = 0; it < pk.max_iter && status == 1; ++it) {
     TZ_FRESH_T();
+    // the tolerances and step-rule constants are read from the kernel-argument segment where they are used (scalar loads) instead
+    // of living in -- and being spilled from -- two dozen scalar registers for the whole kernel
+    TzKargPtr kpi = (TzKargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kpi));
+    const IpmParams& pi = *(const IpmParams*)kpi;
     TZ_STAMP(PH_STEP);
     double w_[MAXR], rp_[MAXR], ds_[MAXR], dl_[MAXR], g_[MAXR], is_[MAXR], il_[MAXR];      // scratch of this iteration only
 #pragma unroll
@@ -1095,10 +1102,10 @@ retry_solve:
     double nrp = 0, sl = 0, z0 = 0;
     TZ_ROWS(k, r) { rp_[k] = TZ_GX(k, r) + s_[k] - TZ_H(k, r); nrp = fmax(nrp, fabs(rp_[k])); sl += s_[k] * l_[k]; }
     tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM, 2>(nrp, sl, z0, red, rpar);
-    const double mu = sl * p.inv_mi;
+    const double mu = sl * pi.inv_mi;
     nrp *= tz_recip(red[13]);
     if (!(mu == mu) || !(nrp == nrp) || mu > 1e200) { status = 2; break; }
-    if ((nrp <= p.tol && mu <= p.mu_tol) || mu <= p.mu_floor) {
+    if ((nrp <= pi.tol && mu <= pi.mu_tol) || mu <= pi.mu_floor) {
       exact_rd();
       double e1 = 0, e2 = 0, e3 = 0;
       for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
@@ -1106,8 +1113,8 @@ retry_solve:
       const double nrd = e1 * tz_recip(red[12]);
       TZ_STAMP(PH_GEMVT);
       if (!(nrd == nrd)) { status = 2; break; }
-      if (nrd <= p.tol && nrp <= p.tol && mu <= p.mu_tol) { status = 0; px_in_part = true; break; }
-      if (mu <= p.mu_floor) { status = (nrd <= p.tol_loose && nrp <= p.tol_loose) ? 0 : 3; px_in_part = true; break; }
+      if (nrd <= pi.tol && nrp <= pi.tol && mu <= pi.mu_tol) { status = 0; px_in_part = true; break; }
+      if (mu <= pi.mu_floor) { status = (nrd <= pi.tol_loose && nrp <= pi.tol_loose) ? 0 : 3; px_in_part = true; break; }
     }
     // Newton matrix.  is = 1/s, il = 1/lambda are the only two divisions per row and iteration.
     TZ_ROWS(k, r) { is_[k] = tz_recip(s_[k]); il_[k] = tz_recip(l_[k]); w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
@@ -1193,9 +1200,9 @@ retry_solve:
       TZ_ROWS(k, r) muaff += (s_[k] + ap * ds_[k]) * (l_[k] + ad * dl_[k]);
       tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM, 1>(muaff, z1, z2, red, rpar);
     }
-    muaff *= p.inv_mi;
-    const double sfr = (attempt == 0) ? p.step_frac : p.step_frac_retry;
-    if (fmin(ap, ad) >= p.aff_thr && muaff <= p.aff_mu * mu) {
+    muaff *= pi.inv_mi;
+    const double sfr = (attempt == 0) ? pi.step_frac : pi.step_frac_retry;
+    if (fmin(ap, ad) >= pi.aff_thr && muaff <= pi.aff_mu * mu) {
       // the Newton (predictor) step is already (almost) a full step and kills complementarity: take it, skip the corrector
       const double mmA = fmax(mp, md);
       const double alphaA = (mmA > sfr) ? sfr * tz_recip(mmA) : 1.0;
@@ -1253,14 +1260,17 @@ retry_solve:
     goto retry_solve;
   }
   work_s += 1;
+  TzKargPtr kpe = (TzKargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kpe));
+  const IpmParams& pe = *(const IpmParams*)kpe;
   if (step == nsteps - 1) {                 // what a later launch (or the host) reads: solution, multipliers, status
-    for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = xv[c];
-    TZ_ROWS(k, r) { p.s[(size_t)b * mi + r] = s_[k]; p.lam[(size_t)b * mi + r] = l_[k]; }
+    for (int c = t; c < nz; c += TZ_THREADS) pe.x[(size_t)b * nz + c] = xv[c];
+    TZ_ROWS(k, r) { pe.s[(size_t)b * mi + r] = s_[k]; pe.lam[(size_t)b * mi + r] = l_[k]; }
     if (t == 0) {
-      p.status[b] = status; p.iters[b] = it;
-      if (p.shift_policy >= 2) p.shift_state[b] = was_shifted;
-      if (p.status_copy) p.status_copy[b] = status;
-      if (p.work) { atomicAdd(p.work, (unsigned long long)work_f); atomicAdd(p.work + 1, (unsigned long long)work_s); }
+      pe.status[b] = status; pe.iters[b] = it;
+      if (pe.shift_policy >= 2) pe.shift_state[b] = was_shifted;
+      if (pe.status_copy) pe.status_copy[b] = status;
+      if (pe.work) { atomicAdd(pe.work, (unsigned long long)work_f); atomicAdd(pe.work + 1, (unsigned long long)work_s); }
     }
   }
   TZ_STAMP(PH_ELEM);
