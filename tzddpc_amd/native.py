@@ -52,7 +52,7 @@ _lib = None
 
 def build_hint() -> str:
     return ("build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950 -shared -fPIC tzddpc_amd/csrc/tzddpc_hip.hip)")
+            "(python -c 'import __graft_entry__ as g; g.build()', i.e. hipcc --offload-arch=gfx950 -shared -fPIC tzddpc_amd/csrc/tzddpc_hip.hip)")
 
 
 def lib():
