@@ -198,6 +198,28 @@ def test_fused_step_equals_four_kernel_step(built, monkeypatch):
         np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-11, atol=1e-11)
 
 
+def test_single_wave_factor_path_equals_four_wave_path(built, monkeypatch):
+    """nz <= 64 problems factor on one wave while a second wave runs the forward substitution behind it (column counter in LDS)
+    and use the super-step Gram; TZ_CHOL1=0 / TZ_KSPLIT=0 select the four-wave Cholesky with LDS-published solves and the
+    item-plan Gram that larger problems use.  Same arithmetic, different order: closed loops agree to rounding."""
+    from tzddpc_amd.dist import vertex_noise
+    for case, Bn, T in (("di_n20", 96, 12), ("pulley_n10", 48, 8), ("di_n20_k1", 32, 6)):
+        for k in ("TZ_CHOL1", "TZ_KSPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        fast, (A, B, zon) = common.gpu_controller(case)
+        monkeypatch.setenv("TZ_CHOL1", "0"); monkeypatch.setenv("TZ_KSPLIT", "0")
+        slow, _ = common.gpu_controller(case)
+        for k in ("TZ_CHOL1", "TZ_KSPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        slow._native.set_warm_shift(fast.warm_shift_policy)      # same policy on both sides (the calibration is per build)
+        noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
+        x0 = np.tile(zon.X0.center, (Bn, 1))
+        a = fast.simulate_batch(x0, noise, A, B); b = slow.simulate_batch(x0, noise, A, B)
+        assert (a["status"] == 0).all() and (b["status"] == 0).all()
+        np.testing.assert_allclose(a["x"], b["x"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(a["u"], b["u"], rtol=0, atol=1e-9)
+
+
 def test_large_closed_loop_batches_all_solved(built):
     """Every step of every trajectory ends TZ_SOLVED (a handful of pulley steps need the cold restart with the textbook step
     fraction: regression for statuses 3 seen at 4096 trajectories x 40 steps)."""
