@@ -170,6 +170,16 @@ def rank_one_factor(Dd: np.ndarray, tol: float = 1e-12):
     return None
 
 
+def newton_cost(qp: "ParametricQP") -> float:
+    """Cost of one Newton system of the interior point for this formulation: sparse outer products of G'WG, Cholesky, and a
+    per-row term (element-wise work, two slots of LDS and a pass of the ELL products per row) -- used to choose between equivalent
+    formulations; only the order matters."""
+    fu = np.isfinite(qp.u0); fl = np.isfinite(qp.l0)
+    nnz = np.count_nonzero(qp.A, axis=1)
+    rows = np.concatenate([nnz[fu], nnz[fl]])
+    return float((rows.astype(float) ** 2).sum() + qp.nz ** 3 / 3.0 + 100.0 * rows.size)
+
+
 def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: int,
                         build_loss: Callable, build_constraints: Optional[Callable],
                         k0: Optional[int] = None, epigraph: str = "auto") -> ParametricQP:
@@ -177,7 +187,11 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
                  "aggregate" -- when Delta^delta is rank one (rho s'), every radius depends on t_j only through
                                 tau_j = s'|zeta_j|: one variable per step j and 2^(#components) sign rows
                                 tau_j >= sum_c (+-) s_c zeta_{j,c}.  Same feasible (v, xbar) set, far fewer variables;
-                 "auto"      -- aggregate when available and it has at most 32 sign rows per step (n + m <= 5)."""
+                 "group:g"   -- the same with the components dealt into groups of at most g: tau_j = sum_G tau_{j,G},
+                                tau_{j,G} >= sum_{c in G} (+-) s_c zeta_{j,c}: ceil(p / g) variables and at most 2^g rows per
+                                group and step (g = p is "aggregate", g = 1 the component form written in tau);
+                 "auto"      -- rank one: the group size with the cheapest Newton system (`newton_cost` of the assembled
+                                candidates), else "component"."""
     Ahat = np.asarray(Ahat, float); Bhat = np.asarray(Bhat, float)
     K = np.atleast_2d(np.asarray(K, float))
     n, m = Bhat.shape
@@ -227,16 +241,37 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
     tau_var = {}                     # j -> z index                  (aggregate form)
     var_names = [f"v[{k},{j}]" for k in range(N) for j in range(m)]
     nzc = N * m
-    rk1 = rank_one_factor(Dd) if epigraph in ("auto", "aggregate") else None
-    if epigraph == "aggregate" and rk1 is None:
+    rk1 = rank_one_factor(Dd) if epigraph != "component" else None
+    if epigraph != "auto" and epigraph != "component" and rk1 is None:
         raise StructureError("aggregate epigraphs need a rank-one Delta^delta (boxed W x data structure)")
-    aggregate = rk1 is not None and (epigraph == "aggregate" or int(np.count_nonzero(rk1[0])) <= 5)
+    aggregate = rk1 is not None
+    gsize = 0
     if aggregate:
         s_w, c_piv = rk1
+        ncomp = int(np.count_nonzero(s_w > 0))
+        if epigraph == "aggregate":
+            gsize = ncomp
+        elif epigraph.startswith("group:"):
+            gsize = max(1, min(int(epigraph.split(":", 1)[1]), ncomp))
+        else:
+            # "auto": the equivalent formulations are assembled and the cheapest Newton system wins (build time only)
+            best = None
+            for g in range(1, ncomp + 1):
+                if 2 ** g > 64:
+                    break
+                cand = build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N, build_loss, build_constraints, k0, f"group:{g}")
+                c = newton_cost(cand)
+                if best is None or c < best[0]:
+                    best = (c, cand)
+            return best[1]
         for j in range(N):
             if np.any(used[j * p:(j + 1) * p]):
-                tau_var[j] = nzc; nzc += 1
-                var_names.append(f"tau[{j}]")
+                comps = [c for c in range(p) if s_w[c] > 0 and not (j == 0 and c < n)]   # |xbar0| is a parameter
+                groups = [comps[i:i + gsize] for i in range(0, len(comps), gsize)] or [[]]
+                tau_var[j] = []
+                for gi, grp in enumerate(groups):
+                    tau_var[j].append((nzc, grp)); nzc += 1
+                    var_names.append(f"tau[{j}]" if len(groups) == 1 else f"tau[{j},{gi}]")
     else:
         for j in range(N):
             for c in range(p):
@@ -339,8 +374,9 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
             tt = np.zeros(nz)
             th_abs = zeros_t()
             if aggregate:
-                for j, zi in tau_var.items():
-                    tt[zi] = rxT[k][i, j * p + c_piv]            # radius coefficient on tau_j (s normalised to s[c_piv] = 1)
+                for j, grps in tau_var.items():
+                    for zi, _ in grps:
+                        tt[zi] = rxT[k][i, j * p + c_piv]        # radius coefficient on tau_j = sum_G tau_{j,G} (s normalised to s[c_piv] = 1)
             else:
                 for (j, c), zi in t_var.items():
                     tt[zi] = rxT[k][i, j * p + c]
@@ -359,8 +395,9 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
             zc = np.zeros(nz); zc[k * m + j2] = 1.0
             tt = np.zeros(nz); th_abs = zeros_t()
             if aggregate:
-                for j, zi in tau_var.items():
-                    tt[zi] = ruT[k][j2, j * p + c_piv]
+                for j, grps in tau_var.items():
+                    for zi, _ in grps:
+                        tt[zi] = ruT[k][j2, j * p + c_piv]
             else:
                 for (j, c), zi in t_var.items():
                     tt[zi] = ruT[k][j2, j * p + c]
@@ -375,22 +412,23 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
     # ---- tau_j >= s'|zeta_j|  (aggregate form): one row per sign pattern of the components with s_c > 0 -------------
     if aggregate:
         import itertools
-        for j, zi in tau_var.items():
-            comps = [c for c in range(p) if s_w[c] > 0]
-            var_c = [c for c in comps if not (j == 0 and c < n)]          # components that depend on decision variables
-            par_c = [c for c in comps if (j == 0 and c < n)]              # xbar0 components: |xbar0| is a parameter
-            for signs in itertools.product((1.0, -1.0), repeat=len(var_c)):
-                zrow = np.zeros(nz); zrow[zi] = 1.0
-                th = zeros_t()
-                for sg, c in zip(signs, var_c):
-                    if c < n:
-                        zrow[:N * m] -= sg * s_w[c] * Gam[j][c]
-                        th[[ix_x0(cc) for cc in range(n)]] += sg * s_w[c] * Phi[j][c]
-                    else:
-                        zrow[j * m + (c - n)] -= sg * s_w[c]
-                for c in par_c:
-                    th[ix_ax0(c)] += s_w[c]
-                add_row(f"tau[{j}]{''.join('+' if sg > 0 else '-' for sg in signs)}", zrow, 0.0, th, np.inf, zeros_t())
+        for j, grps in tau_var.items():
+            par_c = [c for c in range(p) if s_w[c] > 0 and (j == 0 and c < n)]   # xbar0 components: |xbar0| is a parameter
+            for gi, (zi, var_c) in enumerate(grps):                            # var_c: components that depend on decision variables
+                vname = var_names[zi]
+                for signs in itertools.product((1.0, -1.0), repeat=len(var_c)):
+                    zrow = np.zeros(nz); zrow[zi] = 1.0
+                    th = zeros_t()
+                    for sg, c in zip(signs, var_c):
+                        if c < n:
+                            zrow[:N * m] -= sg * s_w[c] * Gam[j][c]
+                            th[[ix_x0(cc) for cc in range(n)]] += sg * s_w[c] * Phi[j][c]
+                        else:
+                            zrow[j * m + (c - n)] -= sg * s_w[c]
+                    if gi == 0:
+                        for c in par_c:
+                            th[ix_ax0(c)] += s_w[c]
+                    add_row(f"{vname}{''.join('+' if sg > 0 else '-' for sg in signs)}", zrow, 0.0, th, np.inf, zeros_t())
     # ---- t >= |zeta| (component form) ----------------------------------------------------------
     for (j, c), zi in t_var.items():
         zeta = np.zeros(nz); zt = zeros_t()
