@@ -52,7 +52,9 @@ def cpu_baseline(ctl, A, B, zon, horizon, warmup, steps, seconds_budget=40.0):
     so the rate covers the same steps as the GPU number."""
     from oracle.c_oracle import COracle
     from tzddpc_amd.dist import vertex_noise
-    co = COracle(ctl.qp, shift_policy=ctl.warm_shift_policy)        # same warm-start policy as the device chose at build time
+    from tzddpc_amd.builder import horizon_shift
+    pol = int(ctl.warm_shift_policy)       # same warm-start policy as the device chose at build time (the shift maps are data handed to the oracle)
+    co = COracle(ctl.qp, shift_policy=pol, shift_maps=horizon_shift(ctl.qp) if pol else None)
     cores = max(1, min(os.cpu_count() or 1, COracle.max_threads(), 16))
     Wv = zon.W.compute_vertices()
     T = warmup + steps

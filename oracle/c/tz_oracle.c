@@ -236,7 +236,7 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
     mu /= mi; nrd /= scd; nrp /= scp;
     *iters = it;
     if (nrd <= d->tol && nrp <= d->tol && mu <= d->mu_tol) return 0;
-    if (mu <= 1e-3 * d->mu_tol) return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 3;
+    if (mu <= 1e-3 * d->mu_tol) return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 2;   /* mu collapsed before the residuals: numerical */
     if (!(mu == mu) || !(nrd == nrd) || mu > 1e200) return 2;
     for (int r = 0; r < mi; ++r) w[r] = lam[r] / s[r];
     form_H(S, w, d->reg, H, GW);
@@ -270,6 +270,20 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
   return 1;
 }
 
+/* Certificate of primal infeasibility carried by the multipliers of a failed solve: y = lam / max(lam) >= 0 with G'y ~ 0 and
+ * h'y < 0 (Farkas).  Only then is the failure reported as TZ_INFEASIBLE (the reference raises 'Problem is unbounded' for an
+ * infeasible problem, tzddpc/tzddpc.py:374-375); every other failure stays max-iter / numerical. */
+static int farkas(const setup_t* S, const double* h, const double* lam) {
+  int nz = S->nz, mi = S->mi;
+  double lm = 0;
+  for (int r = 0; r < mi; ++r) lm = fmax(lm, lam[r]);
+  if (!(lm > 0) || !isfinite(lm)) return 0;
+  double hy = 0, g = 0;
+  for (int r = 0; r < mi; ++r) hy += h[r] * (lam[r] / lm);
+  for (int c = 0; c < nz; ++c) { double a = 0; for (int r = 0; r < mi; ++r) a += S->G[r * nz + c] * (lam[r] / lm); g = fmax(g, fabs(a)); }
+  return hy < -1e-6 && g <= 1e-6 * fmax(1.0, -hy);
+}
+
 static size_t work_doubles(const tzo_desc* d, const setup_t* S) {
   size_t nz = S->nz, mi = S->mi;
   return nz * nz + mi * nz + 9 * mi + 4 * nz /* ipm */ + d->ntheta + nz + 3 * mi /* theta, q, h, s, lam */ + nz
@@ -301,14 +315,16 @@ static void solve_one(const tzo_desc* d, const setup_t* S, const double* xbar0, 
       d2.step_frac = fmin(d->step_frac, 0.99);
       st = ipm(&d2, S, q, h, x, s, lam, &it2, iw, 0);
       it += it2;
+      if (st != 0 && farkas(S, h, lam)) st = 3;
     }
-  } else { for (int c = 0; c < nz; ++c) x[c] = 0; }
+  }
+  if (st != 0) for (int c = 0; c < nz; ++c) x[c] = 0;     /* failed step: v = 0, i.e. u = K e and the nominal state follows Phi (as the device) */
   *status = st; if (iters) *iters = it;
   double obj = 0;
   for (int c = 0; c < nz; ++c) { double px = 0; for (int k = 0; k < nz; ++k) px += S->P[c * nz + k] * x[k]; obj += x[c] * (0.5 * px + q[c]); }
   double r = d->r0;
   for (int i = 0; i < n; ++i) { r += d->r1[i] * xbar0[i]; for (int j = 0; j < n; ++j) r += xbar0[i] * d->R2[i * n + j] * xbar0[j]; }
-  *cost = (st == 0 || st == 1) ? obj / S->c + r : INFINITY;
+  *cost = (st == 0) ? obj / S->c + r : INFINITY;
   for (int c = 0; c < nv; ++c) v[c] = S->D[c] * x[c];
   for (int rr = 0; rr < (N + 1) * n; ++rr) {
     double a = 0; for (int j = 0; j < n; ++j) a += d->Phi[rr * n + j] * xbar0[j];

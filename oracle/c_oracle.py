@@ -65,7 +65,7 @@ def lib():
 
 
 class COracle:
-    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999, warm_floor=1e-8, warm_gain=1.0, mu_factor=0.1, aff_thr=0.99, aff_mu=1e-3, shift_policy=0):
+    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999, warm_floor=1e-8, warm_gain=1.0, mu_factor=0.1, aff_thr=0.99, aff_mu=1e-3, shift_policy=0, shift_maps=None):
         self.qp = qp
         self._keep = []
         d = Desc()
@@ -85,9 +85,10 @@ class COracle:
         d.mu_tol = float(tol) * float(mu_factor)
         d.aff_thr, d.aff_mu = float(aff_thr), float(aff_mu)
         d.warm_floor, d.warm_gain = float(warm_floor), float(warm_gain)       # warm_floor = 0: every closed-loop step starts cold
-        if shift_policy:                    # same receding-horizon shift of the warm start as the device (TZDDPC.warm_shift_policy)
-            from tzddpc_amd.builder import horizon_shift
-            sv, sr = horizon_shift(qp)
+        if shift_policy:                    # same receding-horizon shift of the warm start as the device (TZDDPC.warm_shift_policy):
+            if shift_maps is None:          # the maps (source variable / source two-sided row) are handed in by the caller
+                raise ValueError("shift_policy != 0 needs shift_maps=(source variable of every variable, source row of every row)")
+            sv, sr = shift_maps
             d.shift_var = self._pin(np.ascontiguousarray(sv, dtype=np.int32)).ctypes.data_as(_ip)
             d.shift_row = self._pin(np.ascontiguousarray(sr, dtype=np.int32)).ctypes.data_as(_ip)
         d.shift_policy = int(shift_policy)

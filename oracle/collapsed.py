@@ -189,7 +189,14 @@ def build_collapsed(A, B, MdataK: MatrixZonotope, Mdelta: MatrixZonotope, K, W: 
             lo.append(s * h); hi.append(np.inf); r_i += 1
     for a, l_, h_ in extra:
         Amat[r_i, :nxi] = a; lo.append(l_); hi.append(h_); r_i += 1
-    return dict(P=P, q=q, r=r0, A=Amat, l=np.array(lo), u=np.array(hi), nxi=nxi, N=N, n=n, m=m, tubes=tubes)
+    # e0-only part of every tube (what the device computes per step from e0): Ze_0 = <e0>, Ze_k >= 1: term1[k-1] = M_K^p <e0>
+    e0tube = [(e0.copy(), np.zeros(n), np.zeros(m))]
+    for k in range(1, N):
+        Z1 = term1[k - 1]
+        e0tube.append((Z1.c.copy(), Z1.rowabs().b0.copy(), Z1.rowabs(K).b0.copy()))
+    # first tube row (dynamics rows come first: (N+1) n equalities), then per step k: n x (ub, lb), m x (ub, lb)
+    return dict(P=P, q=q, r=r0, A=Amat, l=np.array(lo), u=np.array(hi), nxi=nxi, N=N, n=n, m=m, tubes=tubes,
+                e0tube=e0tube, tube_row0=(N + 1) * n)
 
 
 def collapsed_radii(qp, xi):

@@ -36,6 +36,9 @@ def nocons(u, x):
 CASES = {
     # name: (system, loss, constraints, horizon, k0)
     "di_n2": ("di_sim", loss_di, nocons, 2, None),
+    "di_sim_n5": ("di_sim", loss_di, nocons, 5, None),
+    "di_n20_k2": ("di_cc", loss_di, nocons, 20, 2),
+    "di_n80": ("di_cc", loss_di, nocons, 80, None),
     "di_n5": ("di_cc", loss_di, nocons, 5, None),
     "di_n20": ("di_cc", loss_di, nocons, 20, None),
     "di_n20_k1": ("di_cc", loss_di, nocons, 20, 1),
@@ -104,3 +107,50 @@ def oracle_solution(qp, x0, e0, tol=1e-12):
     slack = np.minimum(np.where(np.isfinite(ul), ul - qp.A @ r.x, np.inf), np.where(np.isfinite(ll), qp.A @ r.x - ll, np.inf))
     active = slack < np.abs(r.y)
     return dict(v=v, xbar=xbar, cost=cost, status=r.status, cert=r.cert, active=active, y=r.y, slack=slack)
+
+
+def golden_tube_rows(qp):
+    """Product row index of every tube row, keyed like the golden arrays: {(k, component, side): row} with component < n the
+    state rows and n + j the input rows, side 0 upper / 1 lower.  Rows of step 0 are parameter-only in the product (absent)."""
+    import re
+    out = {}
+    pat = re.compile(r"^(X|U)(ub|lb)\[(\d+),(\d+)\]$")
+    for r, name in enumerate(qp.row_names):
+        mt = pat.match(name)
+        if mt:
+            comp = int(mt.group(4)) + (qp.n if mt.group(1) == "U" else 0)
+            out[(int(mt.group(3)), comp, 0 if mt.group(2) == "ub" else 1)] = r
+    return out
+
+
+def host_controller_from_golden(case, g):
+    """Host-only product controller (no GPU) identified from a golden file's data set and gain."""
+    from tzddpc_amd import TZDDPC, Data, Theta
+    from tzddpc_amd.harness import system
+    sysname, loss, cons, N, k0 = CASES[case]
+    A, B, zon, T = system(sysname)
+    ctl = TZDDPC.__new__(TZDDPC)
+    ctl.device = 0; ctl._native = None; ctl.qp = None
+    ctl.update_identification_data(Data(g["data_u"], g["data_x"]))
+    ctl.build_zonotopes_theta(zon, theta=Theta(g["K"], np.zeros_like(A), np.zeros_like(B)))
+    return ctl, (A, B, zon)
+
+
+def qp_from_golden(case, g, epigraph="auto"):
+    from tzddpc_amd.builder import build_parametric_qp
+    sysname, loss, cons, N, k0 = CASES[case]
+    ctl, (A, B, zon) = host_controller_from_golden(case, g)
+    n = ctl.dim_x
+    Xi, Ui = zon.X.interval, zon.U.interval
+    return build_parametric_qp(ctl.Mdata.center[:, :n], ctl.Mdata.center[:, n:], ctl.MdataK.center,
+                               ctl.MdataK.single_entry_magnitudes(), ctl.Mdelta.single_entry_magnitudes(), ctl.theta.K,
+                               zon.W.center, zon.W.generators, Xi.left_limit, Xi.right_limit, Ui.left_limit, Ui.right_limit,
+                               N, loss, cons, k0, epigraph=epigraph)
+
+
+def c_oracle_for(ctl, **kw):
+    """Plain-C oracle on the controller's QP with the warm-start policy the device chose (the shift maps are data handed to it)."""
+    from oracle.c_oracle import COracle
+    from tzddpc_amd.builder import horizon_shift
+    pol = kw.pop("shift_policy", ctl.warm_shift_policy)
+    return COracle(ctl.qp, shift_policy=pol, shift_maps=horizon_shift(ctl.qp) if pol else None, **kw)

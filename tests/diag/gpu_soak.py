@@ -10,7 +10,7 @@ for case, Bn, T in (("di_n20", 1024, 2000), ("pulley_n10", 1024, 1000)):
     x0 = np.tile(zon.X0.center, (Bn, 1))
     t0 = time.perf_counter(); dev = ctl.simulate_batch(x0, noise, A, B); dt = time.perf_counter() - t0
     ns = 48
-    ref = COracle(ctl.qp, shift_policy=ctl.warm_shift_policy).simulate_batch(x0[:ns], noise[:ns], A, B, threads=16)
+    ref = common.c_oracle_for(ctl).simulate_batch(x0[:ns], noise[:ns], A, B, threads=16)
     err = np.abs(dev["x"][:ns] - ref["x"]).max(axis=(0, 2))
     print(f"{case}: {Bn} x {T} steps in {dt:.2f} s ({Bn * T / dt:,.0f} steps/s incl. host copies), unsolved {int((dev['status'] != 0).sum())}, "
           f"oracle unsolved {int((ref['status'] != 0).sum())}, max |x_dev - x_oracle| {err.max():.2e} (at step {err.argmax()}), last 100 steps {err[-100:].max():.2e}")

@@ -26,23 +26,84 @@ def _ctl_from_golden(case):
     return ctl, g, (A, B, zon)
 
 
-@pytest.mark.parametrize("case", ["di_n2", "di_n5", "di_n20", "di_n20_k1", "pulley_n10", "dim5_n20"])
+GOLDEN_CASES = ["di_n2", "di_sim_n5", "di_n5", "di_n20", "di_n20_k1", "di_n20_k2", "pulley_n10", "dim5_n20"]
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
 def test_golden_parity(built, case):
+    """Device solve against the oracle-only goldens (tests/golden/make_golden.py): cost, consumed input / state, active tube rows."""
     ctl, g, _ = _ctl_from_golden(case)
     out = ctl.solve_batch(g["x0"], g["e0"], want_active=True)
     assert (out["status"] == 0).all(), out["status"]
     scale = 1.0 + np.abs(g["xbar"]).max()
+    rows = common.golden_tube_rows(ctl.qp)
     for b in range(4):
         assert abs(out["cost"][b] - g["cost"][b]) <= 1e-7 * (1 + abs(g["cost"][b]))
         np.testing.assert_allclose(out["v"][b, 0], g["v"][b, 0], atol=REL * (1 + np.abs(g["v"][b]).max()))   # consumed input
         np.testing.assert_allclose(out["xbar"][b, 1], g["xbar"][b, 1], atol=REL * scale)                        # consumed state
         # active set: identical wherever the oracle's complementarity is not borderline
-        slack, y = g["slack"][b], np.abs(g["y"][b])
-        clear = (np.maximum(slack, y) > 1e-8) & ((slack < 1e-2 * y) | (y < 1e-2 * slack))
-        assert np.array_equal(out["active"][b].astype(bool)[clear], g["active"][b][clear])
+        act = out["active"][b].astype(bool)
+        checked = 0
+        for (k, c, side), r in rows.items():
+            sl, y = g["slack"][b, k, c, side], g["y"][b, k, c, side]
+            if max(sl, y) > 1e-8 and (sl < 1e-2 * y or y < 1e-2 * sl):
+                assert act[r] == bool(g["active"][b, k, c, side]), (case, b, k, c, side)
+                checked += 1
+        assert checked > len(rows) // 2
     if case.startswith("di_") and common.CASES[case][4] is None:   # full problem: strictly convex in xbar_1..xbar_{N-1}
         N = common.CASES[case][3]
         np.testing.assert_allclose(out["xbar"][:, :N], g["xbar"][:, :N], atol=5e-6 * scale)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_tube_theta_matches_oracle(built, case):
+    """K1 (tz_tube_kernel): the e0-dependent part of every tube -- centre C_K^p e0, radii of M_K^p <e0> and of K M_K^p <e0>
+    (reference tzddpc/tzddpc.py:172-181, 191-192) -- as left in theta by the device against the oracle's collapsed recursion
+    stored with the goldens, <= 1e-12 absolute."""
+    ctl, g, _ = _ctl_from_golden(case)
+    out = ctl.solve_batch(g["x0"], g["e0"])
+    n, m, N = ctl.qp.n, ctl.qp.m, ctl.qp.N
+    for b in range(4):
+        th = ctl._native.debug_fetch(b, 0)
+        assert th.size == 2 * n + N * (2 * n + m)
+        np.testing.assert_array_equal(th[:n], g["x0"][b]); np.testing.assert_array_equal(th[n:2 * n], np.abs(g["x0"][b]))
+        blk = th[2 * n:].reshape(N, 2 * n + m)
+        np.testing.assert_allclose(blk[:, :n], g["e0_c"][b], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(blk[:, n:2 * n], g["e0_rx"][b], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(blk[:, 2 * n:], g["e0_ru"][b], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("sysname", ["di_sim", "pulley", "dim5_w001"])
+def test_tube_theta_matches_literal_generator_stacking(built, sysname):
+    """The same device numbers against LITERAL stacking (oracle.zonolite: MatrixZonotope * Zonotope multiplies the generator
+    count by gamma_K + 1 per product, exactly like the reference's :175,181) for N = 4 (powers 0..3) on all three systems."""
+    from oracle import harness as H
+    from oracle.zonolite import Zonotope as OZ
+    from tzddpc_amd import TZDDPC, Data, Theta
+    from tzddpc_amd.harness import system
+    s = H.system(sysname)
+    rng = np.random.default_rng(25)
+    u, x = H.generate_trajectories(s["A"], s["B"], s["X0"], s["U"], s["W"], 1, s["T"], rng)
+    idn = H.identify(u, x, s["W"])
+    A, B, zon, T = system(sysname)
+    n, m = B.shape
+    ctl = TZDDPC(Data(u, x))
+    ctl.build_zonotopes_theta(zon, theta=Theta(idn["K"], np.zeros_like(A), np.zeros_like(B)))
+    loss = {"di_sim": common.loss_di, "pulley": common.loss_pulley, "dim5_w001": common.loss_dim5}[sysname]
+    N = 4
+    ctl.build_problem(N, loss, common.cons_dim5 if sysname.startswith("dim5") else common.nocons)
+    Bn = 6
+    x0 = np.tile(zon.X0.center, (Bn, 1)); e0 = 0.02 * rng.standard_normal((Bn, n))
+    ctl.solve_batch(x0, e0)                                  # status irrelevant: theta is formed before the solve
+    for b in range(Bn):
+        blk = ctl._native.debug_fetch(b, 0)[2 * n:].reshape(N, 2 * n + m)
+        Z = OZ(e0[b], np.zeros((n, 1)))
+        for k in range(N):
+            if k > 0:
+                Z = idn["MdataK"] * Z                         # literal: [C Z, G_1 Z, ..., G_gamma Z]
+            np.testing.assert_allclose(blk[k, :n], Z.center, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(blk[k, n:2 * n], np.abs(Z.generators).sum(axis=1), rtol=0, atol=1e-12)
+            np.testing.assert_allclose(blk[k, 2 * n:], np.abs(idn["K"] @ Z.generators).sum(axis=1), rtol=0, atol=1e-12)
 
 
 def test_full_size_against_c_oracle(built):
@@ -83,17 +144,23 @@ def test_determinism_and_batch_independence(built):
 
 def test_solve_api_matches_reference_surface(built):
     ctl, (A, B, zon) = common.gpu_controller("di_n2")
-    xbar0 = zon.X0.center.copy(); e0 = np.zeros(2)
+    xbar0 = zon.X0.center.copy(); e0 = np.array([0.01, -0.005])
     result, v, xbark, Zek = ctl.solve(xbar0, e0, verbose=False)
     assert isinstance(result, float) and v.shape == (2, 1) and xbark.shape == (3, 2)
     Z = Zek.Z.value                                             # examples/1.double_integrator_sim.py:89-90
     assert Z.shape == (2, 1 + 24)                               # Gamma_1 = 24 for the double integrator
     ref = common.oracle_solution(ctl.qp, xbar0, e0)
     assert abs(result - ref["cost"]) <= 1e-8 * (1 + abs(ref["cost"]))
-    # interval hull of the literal Ze[1] equals the collapsed radius used in the constraints
-    from tzddpc_amd.builder import theta_reference
-    rad = np.abs(Z[:, 1:]).sum(axis=1)
-    assert np.all(np.isfinite(rad)) and np.all(rad > 0)
+    # interval hull of the literal Ze[1] equals the collapsed centre / radius the constraints of step 1 use (oracle side:
+    # the same data set identified by the oracle, its collapsed tubes evaluated at the device's solution)
+    from oracle import collapsed as OC, harness as H
+    s = H.system("di_sim")
+    d = ctl.dataset.original_data
+    idn = H.identify(np.asarray(d.u, float), np.asarray(d.x, float), s["W"], K=ctl.theta.K)
+    cq = OC.build_collapsed(idn["A"], idn["B"], idn["MdataK"], idn["Mdelta"], idn["K"], s["W"], s["X"], s["U"], 2, e0, xbar0, H.loss_di)
+    c1, rx1, _ = OC.collapsed_radii(cq, np.concatenate([xbark.reshape(-1), v.reshape(-1)]))[1]
+    np.testing.assert_allclose(Z[:, 0], c1, atol=1e-10)
+    np.testing.assert_allclose(np.abs(Z[:, 1:]).sum(axis=1), rx1, atol=1e-10)
     with pytest.raises(Exception, match="unbounded"):           # reference :374-375 (also raised for infeasible)
         ctl.solve(np.array([50.0, 0.0]), e0)
 
@@ -112,7 +179,7 @@ def test_closed_loop_golden_and_c_oracle(built):
     noise = vertex_noise(zon.W.compute_vertices(), 0, 64, 15)
     x0 = np.tile(zon.X0.center, (64, 1))
     s1 = ctl2.simulate_batch(x0, noise, A, B)
-    s2 = COracle(ctl2.qp, shift_policy=ctl2.warm_shift_policy).simulate_batch(x0, noise, A, B, threads=16)
+    s2 = common.c_oracle_for(ctl2).simulate_batch(x0, noise, A, B, threads=16)
     assert (s1["status"] == 0).all() and (s2["status"] == 0).all()
     np.testing.assert_allclose(s1["x"], s2["x"], atol=1e-6)
     np.testing.assert_allclose(s1["u"], s2["u"], atol=1e-6)
@@ -234,18 +301,36 @@ def test_large_closed_loop_batches_all_solved(built):
         assert np.all(out["x"] >= Xi.left_limit - 1e-9) and np.all(out["x"] <= Xi.right_limit + 1e-9)
 
 
-@pytest.mark.parametrize("case", ["di_n5", "di_n10", "di_n20", "di_n40"])
-def test_horizon_sweep_against_c_oracle(built, case):
-    """BASELINE config 5 (complexity-scaling reproduction): the same closed loop at N = 5 .. 40 on the device and in the plain-C
-    oracle (N = 80 does not fit the on-chip factor and is refused at build time, see test_unsupported_sizes_fail_loudly)."""
-    from oracle.c_oracle import COracle
+@pytest.mark.parametrize("case,Bn,T", [("pulley_n10", 256, 40), ("dim5_n20", 256, 20), ("di_n20_k1", 128, 20), ("di_n20_k2", 128, 20)])
+def test_closed_loop_configs_against_c_oracle(built, case, Bn, T):
+    """BASELINE configs 3 and 4 (and the simplified problems of config 5) in closed loop at their real shapes: every state and
+    input of every trajectory against the plain-C oracle's closed loop of the same QP, 1e-6."""
     from tzddpc_amd.dist import vertex_noise
     ctl, (A, B, zon) = common.gpu_controller(case)
-    Bn, T = 48, 10
     noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
     x0 = np.tile(zon.X0.center, (Bn, 1))
     dev = ctl.simulate_batch(x0, noise, A, B)
-    ref = COracle(ctl.qp, shift_policy=ctl.warm_shift_policy).simulate_batch(x0, noise, A, B, threads=16)
+    ref = common.c_oracle_for(ctl).simulate_batch(x0, noise, A, B, threads=16)
+    assert (dev["status"] == 0).all() and (ref["status"] == 0).all()
+    sx = 1 + np.abs(ref["x"]).max(); su = 1 + np.abs(ref["u"]).max()
+    np.testing.assert_allclose(dev["x"], ref["x"], rtol=0, atol=REL * sx)
+    np.testing.assert_allclose(dev["u"], ref["u"], rtol=0, atol=REL * su)
+    Xi = zon.X.interval
+    assert np.all(dev["x"] >= Xi.left_limit - 1e-9) and np.all(dev["x"] <= Xi.right_limit + 1e-9)
+
+
+@pytest.mark.parametrize("case", ["di_n5", "di_n10", "di_n20", "di_n40", "di_n80"])
+def test_horizon_sweep_against_c_oracle(built, case):
+    """BASELINE config 5 (complexity-scaling reproduction): the same closed loop at N = 5 .. 80 on the device and in the plain-C
+    oracle."""
+    from oracle.c_oracle import COracle
+    from tzddpc_amd.dist import vertex_noise
+    ctl, (A, B, zon) = common.gpu_controller(case)
+    Bn, T = (48, 10) if case != "di_n80" else (24, 6)
+    noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
+    x0 = np.tile(zon.X0.center, (Bn, 1))
+    dev = ctl.simulate_batch(x0, noise, A, B)
+    ref = common.c_oracle_for(ctl).simulate_batch(x0, noise, A, B, threads=16)
     assert (dev["status"] == 0).all() and (ref["status"] == 0).all()
     np.testing.assert_allclose(dev["x"], ref["x"], atol=1e-6)
     np.testing.assert_allclose(dev["u"], ref["u"], atol=1e-6)
@@ -276,6 +361,27 @@ def test_infeasible_trajectories_are_flagged_not_fatal(built, monkeypatch):
     np.testing.assert_array_equal(good_alone["x"], a["x"][~bad])          # trajectories do not influence each other
 
 
+def test_failures_map_to_the_reference_exceptions(built):
+    """A problem that is infeasible beyond the parameter rows (the tube cannot be kept inside X from this state) ends with a
+    Farkas certificate in the multipliers -> TZ_INFEASIBLE -> 'Problem is unbounded' (reference :374-375); a solve that merely
+    runs out of iterations is the reference's SolverError path (:368-371).  No failed iterate is ever returned."""
+    from oracle.c_oracle import COracle
+    ctl, (A, B, zon) = common.gpu_controller("di_n20")
+    x0 = np.array([[-9.5, -2.5], [-7.0, -2.9], [-5.0, -2.0]]); e0 = np.zeros((3, 2))
+    out = ctl.solve_batch(x0, e0)
+    ref = COracle(ctl.qp).solve_batch(x0, e0)
+    assert list(out["status"]) == [3, 3, 0] and list(ref["status"]) == [3, 3, 0]
+    assert np.isinf(out["cost"][:2]).all() and np.all(out["v"][:2] == 0.0)
+    with pytest.raises(Exception, match="unbounded"):
+        ctl.solve(x0[0], e0[0])
+    short, _ = common.gpu_controller("di_n20")
+    short.build_problem(20, common.loss_di, common.nocons, max_iter=3)
+    with pytest.raises(Exception, match="Error while solving the TZDDPC problem"):
+        short.solve(x0[2], e0[2])
+    assert short.last_status == 1
+    os.remove("zpc_logs.txt")
+
+
 def test_warm_shift_policies_agree(built):
     """The receding-horizon shift of the warm start changes the number of iterations, not the trajectories; the C oracle follows
     the same policy step by step."""
@@ -294,7 +400,7 @@ def test_warm_shift_policies_agree(built):
         work[pol] = ctl._native.work_get()["factorizations"]
         ctl._native.timing_enable(False)
         assert (runs[pol]["status"] == 0).all()
-        ref = COracle(ctl.qp, shift_policy=pol).simulate_batch(x0, noise, A, B, threads=16)
+        ref = common.c_oracle_for(ctl, shift_policy=pol).simulate_batch(x0, noise, A, B, threads=16)
         np.testing.assert_allclose(runs[pol]["x"], ref["x"], atol=1e-6)
     ctl._native.set_warm_shift(ctl.warm_shift_policy)
     np.testing.assert_allclose(runs[1]["x"], runs[0]["x"], atol=1e-6)
@@ -317,8 +423,9 @@ def test_reference_example_loop_runs_unchanged(built):
 
 
 def test_unsupported_sizes_fail_loudly(built):
-    """Horizon 80 of the double integrator needs 312 variables: refused at build time with a clear message, not mis-solved."""
+    """Sizes beyond the kernel's limits (here: horizon 200 of the double integrator, 398 variables / 2734 rows) are refused at
+    build time with a clear message, not mis-solved.  N = 80 (BASELINE config 5) is inside the limits."""
     from tzddpc_amd import native
     ctl, (A, B, zon) = common.gpu_controller("di_n5")
     with pytest.raises(native.NativeError, match="not supported"):
-        ctl.build_problem(80, common.loss_di, common.nocons)
+        ctl.build_problem(200, common.loss_di, common.nocons)

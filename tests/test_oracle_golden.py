@@ -1,42 +1,100 @@
-"""-m "not gpu": the committed golden vectors are re-derived by the oracle (certificates recomputed from the stored point)."""
+"""-m "not gpu": the committed golden vectors (provenance: oracle only, tests/golden/make_golden.py) against
+  * the oracle itself (they regenerate), * the product's identification on the same data sets, * the product's builder
+(its QP solved by the oracle's solver must have the golden optimum)."""
 import os
 
 import numpy as np
 import pytest
 
-from oracle.qp_ipm import kkt_certificate
 from tests import common
-from tzddpc_amd.builder import theta_reference
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALL = ["di_n2", "di_sim_n5", "di_n5", "di_n20", "di_n20_k1", "di_n20_k2", "pulley_n10", "dim5_n20"]
 
 
-@pytest.mark.parametrize("case", ["di_n2", "di_n5", "di_n20", "di_n20_k1", "pulley_n10", "dim5_n20"])
-def test_golden_points_satisfy_kkt(case):
+def _make_golden():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("case", ALL)
+def test_goldens_regenerate_from_the_oracle(case):
+    mg = _make_golden()
     g = np.load(os.path.join(GOLD, f"{case}.npz"))
-    ctl, qp, (A, B, zon) = common.identified_qp(case)
-    np.testing.assert_allclose(ctl.dataset.original_data.x, g["data_x"], atol=0)       # fixtures regenerate bit-for-bit
-    np.testing.assert_allclose(ctl.theta.K, g["K"], rtol=1e-12)
-    for b in range(4):
+    assert str(g["provenance"]).startswith("oracle only")
+    sysname, loss, cons, N, k0 = mg.CASES[case]
+    s, u, x, idn = mg.identified(sysname)
+    np.testing.assert_array_equal(x, g["data_x"]); np.testing.assert_array_equal(u, g["data_u"])      # fixtures regenerate bit-for-bit
+    np.testing.assert_allclose(idn["K"], g["K"], rtol=1e-12)
+    b = 1                                                    # one of the four points per case keeps the CPU suite short
+    sol = mg.solve_point(s, idn, N, k0, loss, cons, g["x0"][b], g["e0"][b])
+    assert abs(sol["cost"] - g["cost"][b]) <= 1e-9 * (1 + abs(g["cost"][b]))
+    np.testing.assert_allclose(sol["v"][0], g["v"][b, 0], atol=1e-8)
+    np.testing.assert_allclose(sol["e0_rx"], g["e0_rx"][b], atol=1e-14)
+    assert g["cert"].max() < 1e-9
+
+
+@pytest.mark.parametrize("sysname", ["di_sim", "di_cc", "pulley", "dim5_w001"])
+def test_product_identification_equals_oracle(sysname):
+    """Mdata, MdataK, Mdelta after reduce(1) (reference tzddpc/tzddpc.py:81-83, 119-128) of the product and of
+    oracle.harness.identify on the four benchmark data sets: centres, generators and the boxed magnitudes."""
+    from oracle import harness as H
+    from oracle.collapsed import single_entry_abs
+    from tzddpc_amd import TZDDPC, Data, Theta
+    from tzddpc_amd.harness import system
+    s = H.system(sysname)
+    u, x = H.generate_trajectories(s["A"], s["B"], s["X0"], s["U"], s["W"], 1, s["T"], np.random.default_rng(25))
+    idn = H.identify(u, x, s["W"])
+    A, B, zon, T = system(sysname)
+    ctl = TZDDPC.__new__(TZDDPC); ctl.device = 0; ctl._native = None; ctl.qp = None
+    ctl.update_identification_data(Data(u, x))
+    ctl.build_zonotopes_theta(zon, theta=Theta(idn["K"], np.zeros_like(A), np.zeros_like(B)))
+    for name in ("Mdata", "MdataK", "Mdelta"):
+        mine, ref = getattr(ctl, name), idn[name]
+        np.testing.assert_allclose(mine.center, ref.center, rtol=0, atol=1e-13)
+        assert len(mine.generators) == ref.num_generators
+        np.testing.assert_allclose(np.abs(np.asarray(mine.generators)).sum(axis=0), np.abs(ref.generators).sum(axis=0), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(ctl.MdataK.single_entry_magnitudes(), single_entry_abs(idn["MdataK"]), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(ctl.Mdelta.single_entry_magnitudes(), single_entry_abs(idn["Mdelta"]), rtol=1e-12, atol=1e-15)
+    # the product's default gain (LQR on the identified centre) is the oracle's stand-in gain
+    ctl2 = TZDDPC.__new__(TZDDPC); ctl2.device = 0; ctl2._native = None; ctl2.qp = None
+    ctl2.update_identification_data(Data(u, x))
+    ctl2.build_zonotopes_theta(zon)
+    np.testing.assert_allclose(ctl2.theta.K, idn["K"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("case", ALL)
+def test_product_builder_has_the_golden_optimum(case):
+    """The product's (condensed, grouped-epigraph) QP, assembled from the golden data set and gain and solved by the oracle's
+    solver, has the optimum the oracle found on its own (uncondensed, component-epigraph) statement of the problem."""
+    g = np.load(os.path.join(GOLD, f"{case}.npz"))
+    qp = common.qp_from_golden(case, g)
+    rows = common.golden_tube_rows(qp)
+    for b in (0, 2):
         ref = common.oracle_solution(qp, g["x0"][b], g["e0"][b], tol=1e-12)
-        assert abs(ref["cost"] - g["cost"][b]) <= 1e-9 * (1 + abs(g["cost"][b]))
-        np.testing.assert_allclose(ref["v"][0], g["v"][b, 0], atol=1e-7)
-        assert g["cert"][b].max() < 1e-9
-        # stored multipliers certify the stored primal point independently of any solver
-        th = theta_reference(qp, g["x0"][b], g["e0"][b])
-        nv = qp.N * qp.m
-        # rebuild the full decision vector from the oracle (t / s variables are not stored): certificate on the oracle point
-        assert max(ref["cert"]["primal"], ref["cert"]["dual"], ref["cert"]["comp"]) < 1e-9
+        assert ref["status"] == "solved" and max(ref["cert"]["primal"], ref["cert"]["dual"], ref["cert"]["comp"]) < 1e-9
+        assert abs(ref["cost"] - g["cost"][b]) <= 1e-8 * (1 + abs(g["cost"][b]))
+        np.testing.assert_allclose(ref["v"][0], g["v"][b, 0], atol=1e-6 * (1 + np.abs(g["v"][b]).max()))
+        np.testing.assert_allclose(ref["xbar"][1], g["xbar"][b, 1], atol=1e-6 * (1 + np.abs(g["xbar"][b]).max()))
+        # active tube rows agree wherever the golden complementarity is clear-cut
+        for (k, c, side), r in rows.items():
+            sl, y = g["slack"][b, k, c, side], g["y"][b, k, c, side]
+            if max(sl, y) > 1e-8 and (sl < 1e-2 * y or y < 1e-2 * sl):
+                assert bool(ref["active"][r]) == bool(g["active"][b, k, c, side]), (k, c, side)
 
 
 def test_closed_loop_golden_is_consistent():
     g = np.load(os.path.join(GOLD, "di_n2_closed_loop.npz"))
-    ctl, qp, (A, B, zon) = common.identified_qp("di_n2")
+    from oracle import harness as H
+    s = H.system("di_sim")
+    A, B = s["A"], s["B"]
     x, u, noise = g["x"], g["u"], g["noise"]
     # plant recursion of examples/1.double_integrator_sim.py:85 holds along the stored trajectory
     for b in range(x.shape[0]):
         for t in range(u.shape[1]):
             np.testing.assert_allclose(x[b, t + 1], A @ x[b, t] + (B @ u[b, t]) + noise[b, t], atol=1e-12)
-    Xi = zon.X.interval
+    Xi = s["X"].interval
     assert np.all(x >= Xi.left_limit - 1e-9) and np.all(x <= Xi.right_limit + 1e-9)      # robust constraint satisfaction
     assert np.all(np.abs(u) <= 1 + 1e-9)

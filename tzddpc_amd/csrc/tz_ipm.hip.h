@@ -1147,7 +1147,7 @@ retry_solve:
       TZ_STAMP(PH_GEMVT);
       if (!(nrd == nrd)) { status = 2; break; }
       if (nrd <= pi.tol && nrp <= pi.tol && mu <= pi.mu_tol) { status = 0; px_in_part = true; break; }
-      if (mu <= pi.mu_floor) { status = (nrd <= pi.tol_loose && nrp <= pi.tol_loose) ? 0 : 3; px_in_part = true; break; }
+      if (mu <= pi.mu_floor) { status = (nrd <= pi.tol_loose && nrp <= pi.tol_loose) ? 0 : 2; px_in_part = true; break; }   // mu collapsed before the residuals: numerical
     }
     // Newton matrix.  is = 1/s, il = 1/lambda are the only two divisions per row and iteration.
     TZ_ROWS(k, r) { is_[k] = tz_recip(s_[k]); il_[k] = tz_recip(l_[k]); w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
@@ -1320,6 +1320,28 @@ retry_solve:
     __syncthreads();
     goto retry_solve;
   }
+  if (status != 0 && !skip) {
+    // Both attempts failed.  Only a certificate of primal infeasibility carried by the multipliers -- y = lambda / max(lambda) >= 0
+    // with G'y ~ 0 and h'y < 0 (Farkas) -- makes it TZ_INFEASIBLE (the reference raises 'Problem is unbounded' for an infeasible
+    // problem, tzddpc/tzddpc.py:374-375); every other failure stays max-iter / numerical.  The failed iterate is not used:
+    // x = 0, i.e. u = K e and the nominal state follows Phi, exactly like a step whose parameter rows are violated.
+    double lm = 0.0, z1 = 0.0, z2 = 0.0;
+    TZ_ROWS(k, r) lm = fmax(lm, l_[k]);
+    tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX, 1>(lm, z1, z2, red, rpar);
+    const bool lm_ok = lm > 0.0 && lm < 1e300;
+    const double il = lm_ok ? 1.0 / lm : 0.0;
+    double hy = 0.0;
+    TZ_ROWS(k, r) { const double y = lm_ok ? l_[k] * il : 0.0; vin[r] = y; hy += TZ_H(k, r) * y; }
+    __syncthreads();
+    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
+    __syncthreads();
+    double gmax = fabs(tz_ell_colsum(pl, cseg));
+    tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM, 2>(gmax, hy, z2, red, rpar);
+    if (lm_ok && hy < -1e-6 && gmax <= 1e-6 * fmax(1.0, -hy)) status = 3;
+    for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
+    px_in_part = false;
+    __syncthreads();
+  }
   work_s += 1;
   TzKargPtr kpe = (TzKargPtr)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(kpe));
@@ -1361,7 +1383,7 @@ retry_solve:
         r += cr1[i] * x0[i];
         for (int j = 0; j < n; ++j) r += x0[i] * cR2[i * n + j] * x0[j];
       }
-      F.fin.cost[(size_t)b * F.fin.cost_stride + (size_t)step * F.cost_step] = (status == 0 || status == 1) ? acc / F.fin.cost_scale + r : INFINITY;
+      F.fin.cost[(size_t)b * F.fin.cost_stride + (size_t)step * F.cost_step] = (status == 0) ? acc / F.fin.cost_scale + r : INFINITY;
       if (status != 0 && F.plant.sticky && F.plant.sticky[b] == 0) F.plant.sticky[b] = status;
     }
     if (F.fin.v) for (int c = t; c < nv; c += TZ_THREADS) F.fin.v[(size_t)b * nv + c] = dxv[c];

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void tz_finish_kernel(FinishParams p) {
       for (int j = 0; j < n; ++j) r += x0[i] * p.R2[i * n + j] * x0[j];
     }
     const int st = p.status[b];
-    p.cost[(size_t)b * p.cost_stride] = (st == 0 || st == 1) ? acc / p.cost_scale + r : INFINITY;
+    p.cost[(size_t)b * p.cost_stride] = (st == 0) ? acc / p.cost_scale + r : INFINITY;
   }
   double* v = p.v + (size_t)b * nv;
   for (int c = lane; c < nv; c += 64) v[c] = p.Dz[c] * x[c];

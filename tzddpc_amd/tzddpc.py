@@ -260,18 +260,16 @@ class TZDDPC(object):
         v, xbar, cost, status, iters, _ = self._native.solve_batch(np.asarray(xbar0, float).reshape(1, -1),
                                                                   np.asarray(e0, float).reshape(1, -1))
         st = int(status[0])
-        if st in (native.TZ_INFEASIBLE,) or not np.isfinite(cost[0]):
-            if st == native.TZ_NUMERICAL:
-                msg = "Error while solving the TZDDPC problem. Details: numerical failure in the interior-point kernel"
-                with open("zpc_logs.txt", "w") as f:                                        # :369-371
-                    print(msg, file=f)
-                raise Exception(msg)
-            raise Exception("Problem is unbounded")                                          # :374-375 (also infeasible)
-        if st == native.TZ_NUMERICAL:
-            msg = "Error while solving the TZDDPC problem. Details: numerical failure in the interior-point kernel"
-            with open("zpc_logs.txt", "w") as f:
+        self.last_status, self.last_iters = st, int(iters[0])
+        if st in (native.TZ_MAX_ITER, native.TZ_NUMERICAL):
+            # the reference's solver failure path (cvxpy SolverError, :368-371): log file + exception; an unconverged iterate is never returned
+            msg = ("Error while solving the TZDDPC problem. Details: the interior-point kernel "
+                   + ("hit its iteration limit" if st == native.TZ_MAX_ITER else "failed numerically") + f" after {int(iters[0])} iterations")
+            with open("zpc_logs.txt", "w") as f:                                            # :369-371
                 print(msg, file=f)
             raise Exception(msg)
+        if st != native.TZ_SOLVED or not np.isfinite(cost[0]):
+            raise Exception("Problem is unbounded")                                          # :374-375 (also raised for infeasible: +inf)
         self.last_status, self.last_iters = st, int(iters[0])
         return float(cost[0]), v[0], xbar[0], self._ze1(np.asarray(xbar0, float).reshape(-1), np.asarray(e0, float).reshape(-1), v[0][0])
 
