@@ -361,8 +361,19 @@ int tzo_solve_batch(const tzo_desc* d, int B, const double* xbar0, const double*
 }
 
 /* closed loop, examples/1.double_integrator_sim.py:75-90 */
+static int tzo_simulate_core(const tzo_desc* d, int B, int T, const double* x0, const double* noise, const double* At, const double* Bt,
+                       double* x_traj, double* u_traj, double* cost, int32_t* status, int threads, int32_t* iters_out);
 int tzo_simulate_batch(const tzo_desc* d, int B, int T, const double* x0, const double* noise, const double* At, const double* Bt,
                        double* x_traj, double* u_traj, double* cost, int32_t* status, int threads) {
+  return tzo_simulate_core(d, B, T, x0, noise, At, Bt, x_traj, u_traj, cost, status, threads, NULL);
+}
+/* the same with the interior-point iterations of every step (B x T) reported */
+int tzo_simulate_batch_iters(const tzo_desc* d, int B, int T, const double* x0, const double* noise, const double* At, const double* Bt,
+                       double* x_traj, double* u_traj, double* cost, int32_t* status, int threads, int32_t* iters_out) {
+  return tzo_simulate_core(d, B, T, x0, noise, At, Bt, x_traj, u_traj, cost, status, threads, iters_out);
+}
+static int tzo_simulate_core(const tzo_desc* d, int B, int T, const double* x0, const double* noise, const double* At, const double* Bt,
+                       double* x_traj, double* u_traj, double* cost, int32_t* status, int threads, int32_t* iters_out) {
   setup_t* S = make_setup(d);
   size_t wd = work_doubles(d, S);
   int n = d->n, m = d->m, N = d->N;
@@ -388,6 +399,7 @@ int tzo_simulate_batch(const tzo_desc* d, int B, int T, const double* x0, const 
         was_shifted = (wmode == 3);
         solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk, wmode);
         prev_it = it;
+        if (iters_out) iters_out[(size_t)b * T + t] = it;
         prev_ok = (st == 0) && d->warm_floor > 0;
         if (!sticky && st) sticky = st;
         if (cost) cost[(size_t)b * T + t] = c;

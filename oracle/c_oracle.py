@@ -65,7 +65,7 @@ def lib():
 
 
 class COracle:
-    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999, warm_floor=1e-8, warm_gain=1.0, mu_factor=0.1, aff_thr=0.99, aff_mu=1e-3, shift_policy=0, shift_maps=None):
+    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999, warm_floor=1e-8, warm_gain=1.0, mu_factor=0.3, aff_thr=0.99, aff_mu=1e-3, shift_policy=0, shift_maps=None):
         self.qp = qp
         self._keep = []
         d = Desc()
@@ -113,12 +113,16 @@ class COracle:
         lib().tzo_solve_batch(C.byref(self.d), B, p(xbar0), p(e0), p(v), p(xbar), p(cost), p(status), p(iters), p(active), int(threads))
         return dict(v=v, xbar=xbar, cost=cost, status=status, iters=iters, active=active)
 
-    def simulate_batch(self, x0, noise, A_true, B_true, threads: int = 1):
+    def simulate_batch(self, x0, noise, A_true, B_true, threads: int = 1, want_iters: bool = False):
         qp = self.qp
         x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, qp.n); B = x0.shape[0]
         noise = np.ascontiguousarray(noise, dtype=np.float64).reshape(B, -1, qp.n); T = noise.shape[1]
         At = np.ascontiguousarray(A_true, dtype=np.float64); Bt = np.ascontiguousarray(B_true, dtype=np.float64).reshape(qp.n, qp.m)
         xt = np.empty((B, T + 1, qp.n)); ut = np.empty((B, T, qp.m)); cost = np.empty((B, T)); status = np.empty(B, dtype=np.int32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
+        if want_iters:
+            iters = np.zeros((B, T), dtype=np.int32)
+            lib().tzo_simulate_batch_iters(C.byref(self.d), B, T, p(x0), p(noise), p(At), p(Bt), p(xt), p(ut), p(cost), p(status), int(threads), p(iters))
+            return dict(x=xt, u=ut, cost=cost, status=status, iters=iters)
         lib().tzo_simulate_batch(C.byref(self.d), B, T, p(x0), p(noise), p(At), p(Bt), p(xt), p(ut), p(cost), p(status), int(threads))
         return dict(x=xt, u=ut, cost=cost, status=status)

@@ -403,8 +403,9 @@ def test_warm_shift_policies_agree(built):
         ref = common.c_oracle_for(ctl, shift_policy=pol).simulate_batch(x0, noise, A, B, threads=16)
         np.testing.assert_allclose(runs[pol]["x"], ref["x"], atol=1e-6)
     ctl._native.set_warm_shift(ctl.warm_shift_policy)
-    np.testing.assert_allclose(runs[1]["x"], runs[0]["x"], atol=1e-6)
-    np.testing.assert_allclose(runs[3]["x"], runs[0]["x"], atol=1e-6)
+    sx = REL * (1 + np.abs(runs[0]["x"]).max())             # two runs that are each within the north-star tolerance of the optimum
+    np.testing.assert_allclose(runs[1]["x"], runs[0]["x"], rtol=0, atol=sx)
+    np.testing.assert_allclose(runs[3]["x"], runs[0]["x"], rtol=0, atol=sx)
     assert work[3] < work[0]                      # the transient from X0 is what the shift is for
 
 

@@ -56,6 +56,9 @@ struct IpmParams {
                               // and for as long as the shifted steps that follow finish in one iteration
   int* shift_state;           // per trajectory: was the last warm start shifted (carried across launches)
   const int* sx; const int* sr; const double* sxs; const double* sls;   // source variable / row and rescaling, see tz_problem_desc
+  // problems with more than 64 variables (tz_tt.hip.h): H in the tile-triangle layout, TS doubles per tile, blocked Gram plan
+  int TS, ntile, gu;       // gu: tiles per side of a unit of the blocked Gram
+  const struct TzGUnit* gunits; const int* gunit_ptr;      // units of the blocked Gram, grouped per wave (TZ_NWAVES + 1 offsets)
   int chol1;                  // Tz <= 16: one wave factors H while the other three form the predictor's right-hand side
   int ksplit;                 // Gram by tz_form_H_ksplit (Tz <= TZ_KS_TZ) instead of the item plan
   int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
@@ -852,9 +855,19 @@ __device__ inline bool tz_fwd_trailing(const IpmParams& p, const double* Hq, con
   return ok;
 }
 
-// LDS footprint in doubles (host mirrors this in tzddpc_hip.hip)
-__host__ __device__ inline size_t tz_ipm_lds_doubles(int nquads, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit, int ntube, int nell, int park = 0) {
-  return (park ? 2 * (size_t)mip : 0) + (ksplit ? (size_t)nquads * TZ_QSTR : 0) + (size_t)nquads * TZ_QSTR + (size_t)Tz * 16 + 14 * (size_t)nzp + (size_t)(mip + 4) + 32 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 4 * TZ_NMAX + (size_t)ntube + (size_t)nell;
+#include "tz_tt.hip.h"
+// unit size of the blocked Gram by register budget (MINW = workgroups per CU the variant is compiled for: 2 -> 256 registers,
+// 1 -> 512) and super-steps in flight; the host plans its units with the same size (tzddpc_hip.hip)
+#ifndef TZ_TT_NST
+#define TZ_TT_NST 4
+#endif
+#define TZ_TT_GU(minw) ((minw) >= 2 ? 6 : 8)
+
+// LDS footprint in doubles (host mirrors this in tzddpc_hip.hip).  hsize: doubles of the factor storage -- nquads * TZ_QSTR in the
+// quad layout (nz <= 64), ntile * TS in the tile-triangle layout; the latter keeps 16 more doubles behind dinv for the factor of
+// the diagonal tile being eliminated (tz_cholesky_tt).
+__host__ __device__ inline size_t tz_ipm_lds_doubles(size_t hsize, int tt, int Tz, int nzp, int mip, int nklist, int ntheta, int ksplit, int ntube, int nell, int park = 0) {
+  return (park ? 2 * (size_t)mip : 0) + (ksplit ? hsize : 0) + hsize + (size_t)Tz * 16 + (tt ? 16 : 0) + 14 * (size_t)nzp + (size_t)(mip + 4) + 32 + 2 + (size_t)((nklist + 1) / 2) + (size_t)ntheta + 4 * TZ_NMAX + (size_t)ntube + (size_t)nell;
 }
 
 typedef __attribute__((address_space(4))) const IpmParams* TzKargPtr;
@@ -887,9 +900,12 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     for (int r = t; r < mi; r += TZ_THREADS) { p.s[(size_t)b * mi + r] = 1.0; p.lam[(size_t)b * mi + r] = 0.0; }
     return;
   }
+  constexpr bool TT = (NCG >= 2);          // more than 64 variables: tile-triangle layout, blocked Gram, two-phase Cholesky (tz_tt.hip.h)
+  const size_t hsize = TT ? (size_t)p.ntile * p.TS : (size_t)p.nquads * TZ_QSTR;
   double* Hq = lds;
-  double* dinv = Hq + (size_t)p.nquads * TZ_QSTR;
-  double* xv = dinv + p.Tz * 16;
+  double* dinv = Hq + hsize;
+  double* dfac = dinv + p.Tz * 16;         // TT only
+  double* xv = dfac + (TT ? 16 : 0);
   double* dxv = xv + nzp;
   double* rdv = dxv + nzp;
   double* r1v = rdv + nzp;
@@ -909,7 +925,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   // 128-register variant: h and G x of the rows live in LDS (each thread touches only its own slots: no barrier) -- two
   // register pairs fewer across the whole solve
   constexpr bool PARK = (MINW == 4);
-  double* hL = Pq + (p.ksplit ? (size_t)p.nquads * TZ_QSTR : 0);
+  double* hL = Pq + (p.ksplit ? hsize : 0);
   double* gL = hL + mip;
 
   // rows owned by this thread
@@ -928,7 +944,8 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   const int cseg = (ccol < nz) ? p.et.seg[ccol] : 0;
 
   // ---- once per launch: constants of the problem into LDS, closed-loop state of the trajectory -------------------------
-  if (p.ksplit) {
+  if (TT) { (void)kl; (void)Pq; }
+  else if (p.ksplit) {
     for (int i = t; i <= ((p.Kc + 3) >> 2); i += TZ_THREADS) kl[i] = p.smask[i];
     for (int e = t; e < p.nquads * 64; e += TZ_THREADS) {                // every entry of every quad (padding tiles: 0)
       const int qd = e >> 6;
@@ -1081,7 +1098,7 @@ retry_solve:
   if (!warm) {
     was_shifted = 0;
     // ---- cold start: (P + G'G + reg) x = -q + G'h, then shift the slacks into the cone
-    tz_gram(p, Hq, Pq, vin, kl);
+    if constexpr (TT) tz_gram_tt<TZ_TT_GU(MINW), TZ_TT_NST>(p, Hq, vin); else tz_gram(p, Hq, Pq, vin, kl);
     __syncthreads();
     TZ_ROWS(k, r) vin[r] = TZ_H(k, r);
     __syncthreads();
@@ -1089,9 +1106,12 @@ retry_solve:
     __syncthreads();
     if (t < nzp) r1v[t] = (t < nz) ? tz_ell_colsum(pl, cseg) - qv[t] : 0.0;
     __syncthreads();
+    if constexpr (TT) { okf = tz_cholesky_tt(p, Hq, dinv, dfac, flag); tz_chol_solve_tt(p, Hq, dinv, r1v, tmpz, xv); }
+    else {
     if (p.chol1) { if (wave0) tz_cholesky_wave(p, Hq, dinv, flag); __syncthreads(); okf = (*flag == 0); }
     else okf = tz_cholesky(p, Hq, dinv, flag);
     if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, xv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
+    }
     tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
     if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; }
   }
@@ -1156,7 +1176,7 @@ retry_solve:
 #if TZ_PRIO_ELEM
     __builtin_amdgcn_s_setprio(0);
 #endif
-    tz_gram(p, Hq, Pq, vin, kl, (PROF && t == 0) ? acc_ph : nullptr);
+    if constexpr (TT) tz_gram_tt<TZ_TT_GU(MINW), TZ_TT_NST>(p, Hq, vin, (PROF && t == 0) ? acc_ph : nullptr); else tz_gram(p, Hq, Pq, vin, kl, (PROF && t == 0) ? acc_ph : nullptr);
     __syncthreads();
     TZ_STAMP(PH_FORM);
     TZ_FRESH_T();
@@ -1167,7 +1187,7 @@ retry_solve:
     __syncthreads();
     bool okc;
     bool have_y = false;                                // tmpz holds y = inv(L) r1 (forward substitution done while factoring)
-    if (p.chol1) {
+    if (!TT && p.chol1) {
       if (wave0) {
 #if TZ_PRIO
         __builtin_amdgcn_s_setprio(TZ_PRIO);                 // the serial stretch of this workgroup: ahead of the co-resident waves
@@ -1217,12 +1237,14 @@ retry_solve:
       }
       __syncthreads();
       TZ_STAMP(PH_GEMVT);
-      okc = tz_cholesky(p, Hq, dinv, flag, (PROF && t == 0) ? acc_ph : nullptr);
+      if constexpr (TT) okc = tz_cholesky_tt(p, Hq, dinv, dfac, flag, (PROF && t == 0) ? acc_ph : nullptr);
+      else okc = tz_cholesky(p, Hq, dinv, flag, (PROF && t == 0) ? acc_ph : nullptr);
       TZ_STAMP(PH_CHOL);
     }
     if (!okc) { status = 2; break; }
     TZ_FRESH_T();
-    if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, have_y ? tmpz : r1v, dxv, have_y); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
+    if constexpr (TT) tz_chol_solve_tt(p, Hq, dinv, r1v, tmpz, dxv);
+    else if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, have_y ? tmpz : r1v, dxv, have_y); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
     tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
@@ -1281,7 +1303,8 @@ retry_solve:
     for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? -rdv[c] - tz_ell_colsum(pl, cseg) : 0.0;
     __syncthreads();
     TZ_STAMP(PH_GEMVT);
-    if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, dxv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
+    if constexpr (TT) tz_chol_solve_tt(p, Hq, dinv, r1v, tmpz, dxv);
+    else if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, dxv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
     tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
@@ -1369,7 +1392,7 @@ retry_solve:
     const bool want_cost = F.cost_step != 0 || step == nsteps - 1;      // a cost that the next step overwrites is not formed
     __syncthreads();
     if (want_cost && !px_in_part) tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
-    for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = cDz[c] * xv[c];
+    for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = cDz[c] * xv[F.fin.vpos ? F.fin.vpos[c] : c];     // v in the caller's order
     __syncthreads();
     double acc = 0.0, z1 = 0.0, z2 = 0.0;
     if (want_cost) {

@@ -157,6 +157,7 @@ struct FinishParams {
   const int* status;
   double* v; double* xbar; double* cost; uint8_t* active;   // active may be null
   size_t cost_stride;
+  const int* vpos;       // device position of v[k, j] in x (staircase ordering of the library); null = identity
 };
 
 struct PlantParams {
@@ -217,13 +218,13 @@ __global__ __launch_bounds__(64) void tz_finish_kernel(FinishParams p) {
     p.cost[(size_t)b * p.cost_stride] = (st == 0) ? acc / p.cost_scale + r : INFINITY;
   }
   double* v = p.v + (size_t)b * nv;
-  for (int c = lane; c < nv; c += 64) v[c] = p.Dz[c] * x[c];
+  for (int c = lane; c < nv; c += 64) v[c] = p.Dz[c] * x[p.vpos ? p.vpos[c] : c];
   double* xb = p.xbar + (size_t)b * (N + 1) * n;
   for (int r = lane; r < (N + 1) * n; r += 64) {
     double a = 0.0;
     for (int j = 0; j < n; ++j) a += p.Phi[(size_t)r * n + j] * x0[j];
     const double* g = p.Gam + (size_t)r * nv;
-    for (int c = 0; c < nv; ++c) a += g[c] * (p.Dz[c] * x[c]);
+    for (int c = 0; c < nv; ++c) a += g[c] * (p.Dz[c] * x[p.vpos ? p.vpos[c] : c]);
     xb[r] = a;
   }
   if (p.active) {

@@ -41,6 +41,10 @@ struct DevBuf {
     return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
   }
   hipError_t upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
+  void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
 };
 
 // Balanced lane-ELL of a sparse matrix for the matrix-vector products of tz_ipm_kernel (TzEll in tz_ipm.hip.h).
@@ -77,23 +81,28 @@ struct DevEll {
     return seg.upload(sg);
   }
   TzEll view() const { return TzEll{L, VL, val.p, idx.p, seg.p}; }
+  void swap(DevEll& o) { val.swap(o.val); idx.swap(o.idx); seg.swap(o.seg); std::swap(L, o.L); std::swap(VL, o.VL); }
 };
 
 struct DevCsr {          // device copy of a tz_affmap (CSR in the ABI) re-laid out as ELL, see TzCsr
   DevBuf<int> col;
   DevBuf<double> val, c0;
   int rows = 0, W = 1;
-  hipError_t upload(const tz_affmap& m) {
+  // perm (may be null): device row i is row perm[i] of the map
+  hipError_t upload(const tz_affmap& m, const int* perm = nullptr) {
     rows = m.rows; W = 1;
     for (int r = 0; r < m.rows; ++r) W = std::max(W, m.ptr[r + 1] - m.ptr[r]);
     std::vector<int> ce((size_t)W * std::max(rows, 1), 0);
-    std::vector<double> ve((size_t)W * std::max(rows, 1), 0.0);
-    for (int r = 0; r < m.rows; ++r)
-      for (int e = m.ptr[r]; e < m.ptr[r + 1]; ++e) { ce[(size_t)(e - m.ptr[r]) * rows + r] = m.col[e]; ve[(size_t)(e - m.ptr[r]) * rows + r] = m.val[e]; }
+    std::vector<double> ve((size_t)W * std::max(rows, 1), 0.0), cc((size_t)std::max(rows, 1), 0.0);
+    for (int i = 0; i < m.rows; ++i) {
+      const int r = perm ? perm[i] : i;
+      cc[i] = m.c0[r];
+      for (int e = m.ptr[r]; e < m.ptr[r + 1]; ++e) { ce[(size_t)(e - m.ptr[r]) * rows + i] = m.col[e]; ve[(size_t)(e - m.ptr[r]) * rows + i] = m.val[e]; }
+    }
     hipError_t e;
     if ((e = col.upload(ce)) != hipSuccess) return e;
     if ((e = val.upload(ve)) != hipSuccess) return e;
-    return c0.upload(m.c0, (size_t)m.rows);
+    return c0.upload(cc.data(), (size_t)m.rows);
   }
   TzCsr view() const { return TzCsr{rows, W, col.p, val.p, c0.p}; }
 };
@@ -101,21 +110,34 @@ struct DevCsr {          // device copy of a tz_affmap (CSR in the ABI) re-laid 
 enum { K_TUBE = 0, K_IPM = 1, K_FINISH = 2, K_PLANT = 3, K_COUNT = 4 };
 
 typedef void (*ipm_fn_t)(IpmParams);
-template <int R, int W> ipm_fn_t ipm_pick_ncg(int ncg) {
-  // one column group (nz <= 64) always fits four workgroups per CU: only the 128-register variant exists for it
-  switch (ncg) { case 1: return tz_ipm_kernel<R, 1, TZ_MINWAVES>; case 2: return tz_ipm_kernel<R, 2, W>; case 3: return tz_ipm_kernel<R, 3, W>; default: return tz_ipm_kernel<R, 4, W>; }
+// Kernel variants: <rows per thread, 64-column groups, workgroups per CU the register budget is compiled for>.
+//   nz <= 64   (one column group): quad layout, single-wave Cholesky; always fits four workgroups per CU (128 registers).
+//   nz  > 64   tile-triangle layout, blocked Gram, two-phase Cholesky (tz_tt.hip.h): 256 registers (two workgroups per CU) or
+//              512 (one) -- the blocked Gram keeps an 8 x 8 block of tiles in accumulators.
+//   more than 1024 rows (5 or 6 per thread): tile-triangle variants only.
+template <int R> ipm_fn_t ipm_pick_tt(int ncg, int w) {
+  if (w >= 2) { switch (ncg) { case 1: case 2: return tz_ipm_kernel<R, 2, 2>; case 3: return tz_ipm_kernel<R, 3, 2>; default: return tz_ipm_kernel<R, 4, 2>; } }
+  switch (ncg) { case 1: case 2: return tz_ipm_kernel<R, 2, 1>; case 3: return tz_ipm_kernel<R, 3, 1>; default: return tz_ipm_kernel<R, 4, 1>; }
 }
-template <int W> ipm_fn_t ipm_pick_maxr(int maxr, int ncg) {
-  switch (maxr) { case 1: return ipm_pick_ncg<1, W>(ncg); case 2: return ipm_pick_ncg<2, W>(ncg); case 3: return ipm_pick_ncg<3, W>(ncg); default: return ipm_pick_ncg<4, W>(ncg); }
-}
-// wgs_per_cu: how many workgroups of this problem fit in one CU's LDS (the register budget is chosen to match)
-ipm_fn_t ipm_kernel_for(int maxr, int ncg, int wgs_per_cu) {
+// tt (out): the variant uses the tile-triangle layout
+ipm_fn_t ipm_kernel_for(int maxr, int ncg, int wgs_per_cu, bool& tt) {
 #ifdef TZ_ONLY_SMALL      // development builds (assembly study, quick A/B of the bench problem): only the variant for mi <= 256, nz <= 64
+  tt = false;
   return (maxr == 1 && ncg == 1) ? tz_ipm_kernel<1, 1, TZ_MINWAVES> : nullptr;
+#elif defined(TZ_ONLY_TT)  // development builds of the tile-triangle class: -DTZ_ONLY_TT=R,NCG,W  (one variant, seconds to build)
+  tt = true; (void)wgs_per_cu;
+  return tz_ipm_kernel<TZ_ONLY_TT>;
 #else
-  if (wgs_per_cu >= 4) return ipm_pick_maxr<4>(maxr, ncg);
-  if (wgs_per_cu >= 2) return ipm_pick_maxr<2>(maxr, ncg);
-  return ipm_pick_maxr<1>(maxr, ncg);
+  tt = (ncg >= 2 || maxr > 4);
+  if (!tt) {
+    switch (maxr) { case 1: return tz_ipm_kernel<1, 1, TZ_MINWAVES>; case 2: return tz_ipm_kernel<2, 1, TZ_MINWAVES>; case 3: return tz_ipm_kernel<3, 1, TZ_MINWAVES>; default: return tz_ipm_kernel<4, 1, TZ_MINWAVES>; }
+  }
+  switch (maxr) {
+    case 1: return ipm_pick_tt<1>(ncg, wgs_per_cu); case 2: return ipm_pick_tt<2>(ncg, wgs_per_cu); case 3: return ipm_pick_tt<3>(ncg, wgs_per_cu);
+    case 4: return ipm_pick_tt<4>(ncg, wgs_per_cu);
+    case 5: return ncg <= 3 ? tz_ipm_kernel<5, 3, 1> : tz_ipm_kernel<5, 4, 1>;
+    default: return ncg <= 3 ? tz_ipm_kernel<6, 3, 1> : tz_ipm_kernel<6, 4, 1>;
+  }
 #endif
 }
 
@@ -157,9 +179,15 @@ struct tz_problem {
   int lastB = 0;
   bool prof = false;
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
-  double warm_floor = 1e-8, warm_gain = 1.0, mu_factor = 0.1, aff_thr = 0.99, aff_mu = 1e-3;
+  double warm_floor = 1e-8, warm_gain = 1.0, mu_factor = 0.3, aff_thr = 0.99, aff_mu = 1e-3;
   bool warm_enabled = true;
   int ntube = 0;
+  bool tt = false;             // tile-triangle layout / blocked Gram / two-phase Cholesky (nz > 64 or more than 1024 rows)
+  int TS = 16, ntile = 0, gu = 0;
+  size_t hsize = 0;            // doubles of factor storage in LDS
+  DevBuf<TzGUnit> gunits; DevBuf<int> gunit_ptr;
+  DevBuf<int> vpos;            // staircase ordering (tile-triangle class): device position of v[k, j]; null = identity
+  std::vector<int> permc, permr;   // device variable / row i is the caller's permc[i] / permr[i] (empty = identity)
   bool chol1 = false;          // single-wave Cholesky overlapped with the predictor's G' product (Tz <= 16; TZ_CHOL1=0 disables)
   bool ksplit = false;         // Gram by k-split (Tz <= TZ_KS_TZ; TZ_KSPLIT=0 keeps the item plan)
   bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_FUSE=0: four kernels per step, same arithmetic)
@@ -245,6 +273,7 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.inv_mi = 1.0 / p->mi; ip.mu_floor = 1e-3 * ip.mu_tol; ip.tol_loose = 1e3 * p->tol; ip.step_frac_retry = std::min(p->step_frac, 0.99);
   ip.prof = p->prof ? p->prof_buf.p : nullptr;
   ip.work = p->timing ? p->work_buf.p : nullptr;
+  ip.TS = p->TS; ip.ntile = p->ntile; ip.gu = p->gu; ip.gunits = p->gunits.p; ip.gunit_ptr = p->gunit_ptr.p;
   ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0; ip.chol1 = p->chol1 ? 1 : 0; ip.ntube = p->ntube;
   ip.shift_policy = p->have_shift ? p->shift_policy : 0;
   ip.shift_state = p->shift_state.p;
@@ -275,7 +304,7 @@ int launch_step_fused(tz_problem* p, int B, double* d_x, double* d_xbar, double*
   F.qmap = p->q.view(); F.hmap = p->h.view(); F.parmap = p->par.view(); F.par_lo = p->par_lo.p; F.par_hi = p->par_hi.p;
   F.fin = FinishParams{B, p->n, p->m, p->N, p->nz, p->mi, p->nzp, p->nc_rows, p->P.p, p->Dz.p, p->Phi.p, p->Gam.p,
                        p->r1.p, p->R2.p, p->r0, p->cost_scale, p->row_of.p, p->act_scale.p, d_xbar, nullptr, nullptr, nullptr, nullptr,
-                       d_status, nsteps > 1 ? nullptr : p->v.p, nsteps > 1 ? nullptr : p->xbar.p, d_cost, nullptr, cost_stride};
+                       d_status, nsteps > 1 ? nullptr : p->v.p, nsteps > 1 ? nullptr : p->xbar.p, d_cost, nullptr, cost_stride, p->vpos.p};
   F.plant = PlantParams{B, p->n, p->m, p->N, p->K.p, d_A, d_Bm, nullptr, nullptr, d_w, w_stride, d_status, d_x, d_xbar, d_e,
                         d_u, u_stride, d_xout, x_stride, d_sticky};
   hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, p->stream, ip);
@@ -307,7 +336,7 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
     Timer tm(p, K_FINISH);
     FinishParams fp{B, p->n, p->m, p->N, p->nz, p->mi, p->nzp, p->nc_rows, p->P.p, p->Dz.p, p->Phi.p, p->Gam.p,
                     p->r1.p, p->R2.p, p->r0, p->cost_scale, p->row_of.p, p->act_scale.p, d_xbar0, p->qv.p, p->x.p, p->s.p, p->lam.p,
-                    d_status, d_v, d_xbar, d_cost, d_active, cost_stride};
+                    d_status, d_v, d_xbar, d_cost, d_active, cost_stride, p->vpos.p};
     hipLaunchKernelGGL(tz_finish_kernel, dim3(B), dim3(64), 0, st, fp);
   }
   TZ_HIP(hipGetLastError());
@@ -345,6 +374,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (d->n < 1 || d->n > TZ_NMAX || d->m < 1 || d->m > TZ_MMAX) TZ_FAIL(TZ_ERR_UNSUPPORTED, "dim_x must be 1..%d and dim_u 1..%d", TZ_NMAX, TZ_MMAX);
   if (d->N < 1 || d->nz < d->N * d->m || d->mi < 1) TZ_FAIL(TZ_ERR_INVALID, "inconsistent sizes N=%d nz=%d mi=%d", d->N, d->nz, d->mi);
   if (d->nz > 256) TZ_FAIL(TZ_ERR_UNSUPPORTED, "nz=%d > 256 decision variables not supported by tz_ipm_kernel", d->nz);
+  if (d->mi > 6 * TZ_THREADS) TZ_FAIL(TZ_ERR_UNSUPPORTED, "mi=%d > %d inequality rows not supported by tz_ipm_kernel", d->mi, 6 * TZ_THREADS);
   if (d->ntheta != 2 * d->n + d->N * (2 * d->n + d->m)) TZ_FAIL(TZ_ERR_INVALID, "ntheta mismatch");
   if (d->q.rows != d->nz || d->h.rows != d->mi) TZ_FAIL(TZ_ERR_INVALID, "affine map row counts do not match nz / mi");
   for (int k = 0; k < d->N; ++k)
@@ -373,12 +403,40 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   p->nquads = 0;
   for (int I = 0; I < Tz; ++I) p->nquads += (I >> 2) + 1;
 
-  // padded dense copies
-  std::vector<double> P((size_t)nzp * nzp, 0.0), G((size_t)mip * nzp, 0.0), Gt((size_t)nzp * mip, 0.0), Gp((size_t)(Kc + 1) * (Tz + 1) * 16, 0.0);   // tile Tz of every row and the last patch row stay zero (masked operands / prefetch padding)
-  for (int r = 0; r < nz; ++r) for (int c = 0; c < nz; ++c) P[(size_t)r * nzp + c] = d->P[(size_t)r * nz + c];
+  p->maxr = (mi + TZ_THREADS - 1) / TZ_THREADS; p->ncg = (nzp + 63) / 64;
+  p->tt = (p->ncg >= 2 || p->maxr > 4);
+  // Staircase ordering (tile-triangle class): the library keeps the variables in time order (v_k next to the epigraph variables
+  // of step k) and the rows by their last non-zero column, so that the non-zeros of G lie under a staircase: super-step s (16
+  // rows) touches only the tile columns 0 .. cmax[s], non-decreasing in s.  A unit of the blocked Gram is then active on a
+  // contiguous range of super-steps [s0, S) and runs there without a single mask test.  Purely structural: the time of v[k, j]
+  // (the first N m variables, reference tzddpc/tzddpc.py:155) is k, the time of any other variable the smallest, over the rows
+  // it appears in, of the latest input in that row.  Callers never see the ordering (outputs go through vpos / row_of).
+  std::vector<int> permc((size_t)nz), permr((size_t)mi), invc((size_t)nz), invr((size_t)mi);
+  std::iota(permc.begin(), permc.end(), 0); std::iota(permr.begin(), permr.end(), 0);
+  const int nv = d->N * d->m;
+  if (p->tt && getenv("TZ_NO_STAIRCASE") == nullptr) {
+    std::vector<int> rowt((size_t)mi, -1), colt((size_t)nz, 1 << 30);
+    for (int r = 0; r < mi; ++r) for (int c = 0; c < nv; ++c) if (d->G[(size_t)r * nz + c] != 0.0) rowt[r] = std::max(rowt[r], c / d->m);
+    for (int c = 0; c < nv; ++c) colt[c] = c / d->m;
+    for (int c = nv; c < nz; ++c) { for (int r = 0; r < mi; ++r) if (d->G[(size_t)r * nz + c] != 0.0) colt[c] = std::min(colt[c], rowt[r]); if (colt[c] == (1 << 30)) colt[c] = d->N; }
+    std::stable_sort(permc.begin(), permc.end(), [&](int a, int b) { return colt[a] < colt[b]; });
+    for (int i = 0; i < nz; ++i) invc[permc[i]] = i;
+    std::vector<int> last((size_t)mi, -1);
+    for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) if (d->G[(size_t)r * nz + c] != 0.0) last[r] = std::max(last[r], invc[c]);
+    std::stable_sort(permr.begin(), permr.end(), [&](int a, int b) { return last[a] < last[b]; });
+    p->permc = permc; p->permr = permr;
+    std::vector<int> vp((size_t)nv);
+    for (int c = 0; c < nv; ++c) vp[c] = invc[c];
+    TZ_HIP(p->vpos.upload(vp));
+  }
+  for (int i = 0; i < nz; ++i) invc[permc[i]] = i;
+  for (int i = 0; i < mi; ++i) invr[permr[i]] = i;
+  // padded dense copies (device order)
+  std::vector<double> P((size_t)nzp * nzp, 0.0), G((size_t)mip * nzp, 0.0), Gp((size_t)(Kc + 1) * (Tz + 1) * 16, 0.0);   // tile Tz of every row and the last patch row stay zero (masked operands / prefetch padding)
+  for (int r = 0; r < nz; ++r) for (int c = 0; c < nz; ++c) P[(size_t)r * nzp + c] = d->P[(size_t)permc[r] * nz + permc[c]];
   for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) {
-    double v = d->G[(size_t)r * nz + c];
-    G[(size_t)r * nzp + c] = v; Gt[(size_t)c * mip + r] = v;
+    double v = d->G[(size_t)permr[r] * nz + permc[c]];
+    G[(size_t)r * nzp + c] = v;
     Gp[((size_t)(r >> 2) * (Tz + 1) + (c >> 2)) * 16 + 4 * (r & 3) + (c & 3)] = v;
   }
   p->nP = 0;
@@ -439,7 +497,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   {
     const int S = (Kc + 3) / 4;
     std::vector<int> sm((size_t)S + 1, 0);
-    for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) if (G[(size_t)r * nzp + c] != 0.0) sm[r >> 4] |= 1 << (c >> 2);
+    if (Tz <= 31) for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) if (G[(size_t)r * nzp + c] != 0.0) sm[r >> 4] |= 1 << (c >> 2);
     TZ_HIP(p->smask.upload(sm));
   }
   {
@@ -456,7 +514,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (klist.empty()) klist.push_back(0);
   p->nklist = std::max((int)klist.size(), (Kc + 3) / 4 + 1);     // the LDS k-list area doubles as the super-step mask table (ksplit)
   TZ_HIP(p->klist.upload(klist)); TZ_HIP(p->items.upload(items_sorted)); TZ_HIP(p->item_ptr.upload(item_ptr));
-  TZ_HIP(p->q.upload(d->q)); TZ_HIP(p->h.upload(d->h)); TZ_HIP(p->par.upload(d->par));
+  TZ_HIP(p->q.upload(d->q, permc.data())); TZ_HIP(p->h.upload(d->h, permr.data())); TZ_HIP(p->par.upload(d->par));
   TZ_HIP(p->par_lo.upload(d->par_lo, (size_t)p->npar)); TZ_HIP(p->par_hi.upload(d->par_hi, (size_t)p->npar));
   TZ_HIP(p->Dz.upload(d->Dz, (size_t)nz));
   TZ_HIP(p->Phi.upload(d->Phi, (size_t)(d->N + 1) * d->n * d->n));
@@ -508,34 +566,116 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
     TZ_HIP(p->Ttube.upload(T.data(), T.size()));
   }
   TZ_HIP(p->power.upload(d->power, (size_t)d->N));
-  TZ_HIP(p->row_of.upload(d->row_of, (size_t)mi));
+  {
+    std::vector<int> ro((size_t)mi); std::vector<double> as((size_t)mi);
+    for (int i = 0; i < mi; ++i) { ro[i] = d->row_of[permr[i]]; as[i] = d->act_scale[permr[i]]; }
+    TZ_HIP(p->row_of.upload(ro)); TZ_HIP(p->act_scale.upload(as));
+  }
   if (d->shift_var && d->shift_row && d->shift_xscale && d->shift_lscale) {
     for (int c = 0; c < nz; ++c) if (d->shift_var[c] < 0 || d->shift_var[c] >= nz) TZ_FAIL(TZ_ERR_INVALID, "shift_var[%d] out of range", c);
     for (int r = 0; r < mi; ++r) if (d->shift_row[r] < 0 || d->shift_row[r] >= mi) TZ_FAIL(TZ_ERR_INVALID, "shift_row[%d] out of range", r);
-    TZ_HIP(p->shift_var.upload(d->shift_var, (size_t)nz)); TZ_HIP(p->shift_row.upload(d->shift_row, (size_t)mi));
-    TZ_HIP(p->shift_xs.upload(d->shift_xscale, (size_t)nz)); TZ_HIP(p->shift_ls.upload(d->shift_lscale, (size_t)mi));
+    std::vector<int> sv((size_t)nz), sr((size_t)mi); std::vector<double> xs((size_t)nz), ls((size_t)mi);
+    for (int i = 0; i < nz; ++i) { sv[i] = invc[d->shift_var[permc[i]]]; xs[i] = d->shift_xscale[permc[i]]; }
+    for (int i = 0; i < mi; ++i) { sr[i] = invr[d->shift_row[permr[i]]]; ls[i] = d->shift_lscale[permr[i]]; }
+    TZ_HIP(p->shift_var.upload(sv)); TZ_HIP(p->shift_row.upload(sr));
+    TZ_HIP(p->shift_xs.upload(xs)); TZ_HIP(p->shift_ls.upload(ls));
     p->have_shift = true;
   }
-  TZ_HIP(p->act_scale.upload(d->act_scale, (size_t)mi));
 
-  p->ksplit = (p->Tz <= TZ_KS_TZ);
   p->ntube = (d->pmax + 1) * d->n * d->n + std::max(d->pmax, 1) * (d->n + d->m) * d->n         // tube tables
              + 3 * d->n * d->n + 2 * d->n * d->m + d->n + d->n * d->N * d->m + d->N * d->m        // recovery / plant constants
              + (d->N + 1) / 2;                                                                    // power[k] (ints)
-  p->chol1 = (p->Tz <= 16);
-  if (const char* e = getenv("TZ_CHOL1")) { if (e[0] == '0') p->chol1 = false; }
-  if (const char* e = getenv("TZ_KSPLIT")) { if (e[0] == '0') p->ksplit = false; }
-  p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist, p->ntheta, p->ksplit ? 1 : 0, p->ntube, p->nell) * sizeof(double);
-  if (mi > 4 * TZ_THREADS) TZ_FAIL(TZ_ERR_UNSUPPORTED, "mi=%d > %d inequality rows not supported by tz_ipm_kernel", mi, 4 * TZ_THREADS);
-  if (p->lds_bytes > 160 * 1024)
-    TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
-  p->maxr = (mi + TZ_THREADS - 1) / TZ_THREADS; p->ncg = (nzp + 63) / 64;
-  const int wgs_per_cu = (int)((160 * 1024) / std::max<size_t>(p->lds_bytes, 1));
-  p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg, wgs_per_cu);
-  if (wgs_per_cu >= 4 || p->ncg == 1) {    // the 128-register variant parks h and G x of the rows in LDS
-    p->lds_bytes = tz_ipm_lds_doubles(p->nquads, Tz, nzp, mip, p->nklist, p->ntheta, p->ksplit ? 1 : 0, p->ntube, p->nell, 1) * sizeof(double);
-    if (p->lds_bytes > 160 * 1024)
-      TZ_FAIL(TZ_ERR_UNSUPPORTED, "problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", p->lds_bytes, nz, mi);
+  const size_t LDS_MAX = 160 * 1024;
+  auto fail_lds = [&](size_t need) { char b[256]; snprintf(b, sizeof(b), "not supported: the problem needs %zu bytes of LDS per workgroup (nz=%d, mi=%d); limit is 160 KiB", need, nz, mi); g_err = b; return TZ_ERR_UNSUPPORTED; };
+  int wgs_per_cu = 1;
+  if (p->tt) {
+    // ---- tile-triangle class: masks and work plan of the blocked Gram, tile stride, workgroups per CU ----------------------
+    p->ksplit = false; p->chol1 = false;
+    p->ntile = Tz * (Tz + 1) / 2;
+    const int S = (Kc + 3) / 4;
+    // staircase: last non-zero tile column of every super-step, made non-decreasing (it is, when the ordering above is on);
+    // sfirst[I] = first super-step that touches tile column I
+    std::vector<int> cmaxs((size_t)S, -1);
+    for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) if (G[(size_t)r * nzp + c] != 0.0) cmaxs[r >> 4] = std::max(cmaxs[r >> 4], c >> 2);
+    std::vector<int> sfirst((size_t)Tz + 1, S);
+    for (int sIdx = S - 1; sIdx >= 0; --sIdx) for (int I = 0; I <= cmaxs[sIdx]; ++I) sfirst[I] = sIdx;
+    // units: the tile index range is cut into near-equal ranges of at most TZ_GU tiles; a unit is a pair of ranges (row range >=
+    // column range).  Cost = MFMAs it issues (masked); LPT over the waves; the range size with the smallest makespan wins.
+    // units: the tile index range (padded with all-zero tile columns up to a multiple of U) is cut into ranges of exactly U tiles;
+    // a unit is a pair of ranges (row range >= column range).  Cost = MFMAs + loads it issues; LPT over the waves; the U in
+    // [UMAX - 2, UMAX] with the smallest makespan wins.
+    std::vector<TzGUnit> best_units; std::vector<int> best_ptr; double best_span = 1e300; int best_u = 0;
+    auto plan = [&](int UMAX) {
+    best_units.clear(); best_span = 1e300;
+    for (int U = std::max(1, UMAX - 2); U <= UMAX; ++U) {
+      const int nrange = (Tz + U - 1) / U;
+      std::vector<TzGUnit> units; std::vector<double> cost;
+      for (int a = 0; a < nrange; ++a) for (int b = 0; b <= a; ++b) {
+        TzGUnit u{a * U, b * U, sfirst[a * U]};
+        const double per = (a == b) ? 0.5 * U * (U + 1) + 0.4 * U : (double)U * U + 0.4 * 2 * U;   // MFMAs + loads of one super-step
+        units.push_back(u); cost.push_back(per * (S - u.s0 + 3) + 60.0);   // + pipeline fill, fold / store
+      }
+      std::vector<int> order(units.size());
+      std::iota(order.begin(), order.end(), 0);
+      std::sort(order.begin(), order.end(), [&](int x, int y) { return cost[x] > cost[y]; });
+      std::vector<std::vector<int>> per_wave(TZ_NWAVES); double load[TZ_NWAVES] = {0, 0, 0, 0};
+      for (int idx : order) { int w = (int)(std::min_element(load, load + TZ_NWAVES) - load); per_wave[w].push_back(idx); load[w] += cost[idx]; }
+      const double span = *std::max_element(load, load + TZ_NWAVES);
+      if (span < best_span) {
+        best_span = span; best_u = U; best_units.clear(); best_ptr.assign(TZ_NWAVES + 1, 0);
+        for (int w = 0; w < TZ_NWAVES; ++w) { for (int idx : per_wave[w]) best_units.push_back(units[idx]); best_ptr[w + 1] = (int)best_units.size(); }
+      }
+    }
+    };
+    p->nklist = 2;
+    // LDS: two workgroups per CU with the padded tile stride if that fits, else one; the partial-sum buffer of the G x product
+    // shrinks from two virtual lanes per row to one before the tile stride loses its padding
+    auto lds_for = [&](int TS, int nell) { return tz_ipm_lds_doubles((size_t)p->ntile * TS, 1, Tz, nzp, mip, p->nklist, p->ntheta, 0, p->ntube, nell) * sizeof(double); };
+    const int nell_full = p->nell;
+    DevEll eg_small; int nell_small = nell_full;
+    bool small_built = false;
+    auto need_small = [&]() -> hipError_t {
+      if (small_built) return hipSuccess;
+      std::vector<std::vector<std::pair<int, double>>> byrow((size_t)mi);
+      for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) { const double v = G[(size_t)r * nzp + c]; if (v != 0.0) byrow[r].push_back({c, v}); }
+      hipError_t e = eg_small.build(byrow, TZ_THREADS, mi);
+      nell_small = std::max(eg_small.VL, p->et.VL); small_built = true;
+      return e;
+    };
+    struct Cand { int TS; bool small; int wgs; };
+    const Cand cands[] = {{17, false, 2}, {17, true, 2}, {17, false, 1}, {17, true, 1}, {16, true, 1}};
+    bool placed = false;
+    for (const Cand& c : cands) {
+      if (c.small) TZ_HIP(need_small());
+      const size_t need = lds_for(c.TS, c.small ? nell_small : nell_full);
+      if (need * c.wgs <= LDS_MAX) {
+        p->TS = c.TS; wgs_per_cu = c.wgs; p->lds_bytes = need;
+        if (c.small) { p->eg.swap(eg_small); p->nell = nell_small; }
+        placed = true; break;
+      }
+    }
+    if (!placed) { TZ_HIP(need_small()); return fail_lds(lds_for(16, nell_small)); }
+    p->hsize = (size_t)p->ntile * p->TS;
+    bool ttk = false;
+    p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg, wgs_per_cu, ttk);
+    if (p->maxr > 4) wgs_per_cu = 1;                                   // those variants exist for one workgroup per CU only
+    plan(TZ_TT_GU(wgs_per_cu));                                        // unit size <= what the chosen variant's register budget holds
+    if (best_units.empty()) TZ_FAIL(TZ_ERR_UNSUPPORTED, "no Gram plan for Tz=%d", Tz);
+    p->gu = best_u;
+    TZ_HIP(p->gunits.upload(best_units)); TZ_HIP(p->gunit_ptr.upload(best_ptr));
+    p->mfma_gram = (int64_t)best_span; p->mfma_chol = (int64_t)Tz * Tz * Tz / 24; p->mfma_issued = p->mfma_gram * TZ_NWAVES + p->mfma_chol;
+  } else {
+    p->ksplit = (p->Tz <= TZ_KS_TZ);
+    p->chol1 = (p->Tz <= 16);
+    if (const char* e = getenv("TZ_CHOL1")) { if (e[0] == '0') p->chol1 = false; }
+    if (const char* e = getenv("TZ_KSPLIT")) { if (e[0] == '0') p->ksplit = false; }
+    p->hsize = (size_t)p->nquads * TZ_QSTR;
+    // nz <= 64: the 128-register variant, h and G x of the rows parked in LDS
+    p->lds_bytes = tz_ipm_lds_doubles(p->hsize, 0, Tz, nzp, mip, p->nklist, p->ntheta, p->ksplit ? 1 : 0, p->ntube, p->nell, 1) * sizeof(double);
+    if (p->lds_bytes > LDS_MAX) return fail_lds(p->lds_bytes);
+    wgs_per_cu = (int)(LDS_MAX / std::max<size_t>(p->lds_bytes, 1));
+    bool ttk = false;
+    p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg, wgs_per_cu, ttk);
   }
   if (!p->ipm_fn) TZ_FAIL(TZ_ERR_UNSUPPORTED, "this development build (TZ_ONLY_SMALL) carries only the mi <= 256, nz <= 64 kernel");
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
@@ -543,7 +683,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (p->prof && !TZ_PROFILE) TZ_FAIL(TZ_ERR_INVALID, "TZ_PROF=1 needs the diagnostic build of the library (libtzddpc_hip_prof.so)");
   if (const char* e = getenv("TZ_WARM")) { p->warm_enabled = (e[0] != '0'); }
   if (const char* e = getenv("TZ_FUSE")) { p->fuse_enabled = (e[0] != '0'); }
-  if ((size_t)p->pmax * p->n > (size_t)p->nquads * TZ_QSTR) p->fuse_enabled = false;   // tube scratch borrows the factor storage
+  if ((size_t)p->pmax * p->n > p->hsize) p->fuse_enabled = false;   // tube scratch borrows the factor storage
   if (const char* e = getenv("TZ_WARM_FLOOR")) { double v = atof(e); if (v > 0) p->warm_floor = v; }
   if (const char* e = getenv("TZ_WARM_GAIN")) p->warm_gain = atof(e);
   if (const char* e = getenv("TZ_MU_FACTOR")) p->mu_factor = atof(e);
@@ -808,6 +948,11 @@ int tz_debug_fetch(tz_problem* p, int32_t b, int what, double* out, int32_t capa
   }
   if (capacity < len) TZ_FAIL(TZ_ERR_INVALID, "capacity %d < %d", capacity, len);
   TZ_HIP(hipMemcpy(out, src, (size_t)len * sizeof(double), hipMemcpyDeviceToHost));
+  const std::vector<int>* perm = (what == 1 || what == 3) ? &p->permc : ((what == 2 || what == 4 || what == 5) ? &p->permr : nullptr);
+  if (perm && !perm->empty()) {                       // device order -> the caller's order
+    std::vector<double> tmp(out, out + len);
+    for (int i = 0; i < len; ++i) out[(*perm)[i]] = tmp[i];
+  }
   return len;
 }
 
