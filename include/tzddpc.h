@@ -180,6 +180,12 @@ int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, dou
  * integrator N=20: 1; pulley: 0) -- the Python layer calibrates it on a short simulated closed loop at build time. */
 int tz_problem_set_warm_shift(tz_problem* p, int32_t policy);
 
+/* The closed-loop entry points (tz_mpc_step, tz_mpc_run) warm-start every trajectory from the solution the HANDLE holds for it from
+ * the previous call with the same batch size.  Call this when the next call starts a new batch of trajectories (fresh x / xbar / e):
+ * the next step then starts cold, and results and iteration counts no longer depend on what the handle solved before.
+ * (tz_solve_batch and tz_simulate_batch never use the stored state.) */
+int tz_problem_reset_warm(tz_problem* p);
+
 /* Kernel timing with HIP events on the problem's stream (bench.py roofline leg).
  * kernel ids: 0 = tz_prepare, 1 = tz_ipm, 2 = tz_finish, 3 = tz_plant_step */
 int tz_timing_enable(tz_problem* p, int enable);

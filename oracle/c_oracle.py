@@ -42,13 +42,21 @@ def _cpu_tag() -> str:
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "c", "tz_oracle.c")
+    """Rebuild when the library is missing, was built on another CPU (-march=native) or from other sources (content hash of the
+    C file and the Makefile: file times do not survive checkouts and snapshot copies)."""
+    import hashlib
+    cdir = os.path.join(_HERE, "c")
+    h = hashlib.sha256()
+    for name in ("tz_oracle.c", "Makefile"):
+        with open(os.path.join(cdir, name), "rb") as fh:
+            h.update(fh.read())
+    want = _cpu_tag() + "\n" + h.hexdigest()
     tag = os.path.join(_HERE, "_build", "cpu.txt")
-    same_cpu = os.path.exists(tag) and open(tag).read() == _cpu_tag()
-    if force or not same_cpu or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.run(["make", "-s", "-B", "-C", os.path.join(_HERE, "c")], check=True)
+    current = os.path.exists(LIB) and os.path.exists(tag) and open(tag).read() == want
+    if force or not current:
+        subprocess.run(["make", "-s", "-B", "-C", cdir], check=True)
         with open(tag, "w") as f:
-            f.write(_cpu_tag())
+            f.write(want)
     return LIB
 
 

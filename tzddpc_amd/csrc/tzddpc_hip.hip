@@ -869,6 +869,16 @@ int tz_problem_set_warm_shift(tz_problem* p, int32_t policy) {
   return TZ_OK;
 }
 
+int tz_problem_reset_warm(tz_problem* p) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  p->have_prev = false;
+  if (p->Bcap > 0) {
+    TZ_HIP(hipSetDevice(p->device));
+    TZ_HIP(hipMemsetAsync(p->shift_state.p, 0, (size_t)p->Bcap * sizeof(int), p->stream));
+  }
+  return TZ_OK;
+}
+
 int tz_timing_enable(tz_problem* p, int enable) {
   if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
   TZ_HIP(hipSetDevice(p->device));

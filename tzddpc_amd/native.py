@@ -84,6 +84,8 @@ def lib():
     L.tz_simulate_batch.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.tz_mpc_step.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.tz_mpc_run.argtypes = [vp, C.c_int32, C.c_int32] + [vp] * 9
+    L.tz_problem_reset_warm.argtypes = [vp]
+    L.tz_problem_set_warm_shift.argtypes = [vp, C.c_int32]
     L.tz_timing_enable.argtypes = [vp, C.c_int]
     L.tz_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.tz_ipm_plan_info.argtypes = [vp] + [C.POINTER(C.c_int64)] * 5
@@ -91,7 +93,7 @@ def lib():
     L.tz_debug_fetch.argtypes = [vp, C.c_int32, C.c_int, vp, C.c_int32]
     for name in ("tz_device_count", "tz_problem_create", "tz_problem_destroy", "tz_problem_set_stream", "tz_problem_sync",
                  "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run", "tz_timing_enable", "tz_timing_get",
-                 "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch"):
+                 "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch", "tz_problem_reset_warm", "tz_problem_set_warm_shift"):
         getattr(L, name).restype = C.c_int
     if L.tz_abi_version() != TZ_ABI_VERSION:
         raise NativeError(f"ABI mismatch: library {L.tz_abi_version()} vs binding {TZ_ABI_VERSION}")
@@ -102,7 +104,7 @@ def lib():
 EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy",
                     "tz_problem_set_stream", "tz_problem_sync", "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run",
                     "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch",
-                    "tz_problem_set_warm_shift")
+                    "tz_problem_set_warm_shift", "tz_problem_reset_warm")
 
 
 def check(rc: int, what: str):
@@ -248,6 +250,10 @@ class Problem:
 
     def sync(self):
         check(lib().tz_problem_sync(self._h), "tz_problem_sync")
+
+    def reset_warm(self):
+        """The next closed-loop call starts a new batch of trajectories: no warm start from what the handle solved before."""
+        check(lib().tz_problem_reset_warm(self._h), "tz_problem_reset_warm")
 
     def set_warm_shift(self, policy: int):
         check(lib().tz_problem_set_warm_shift(self._h, int(policy)), "tz_problem_set_warm_shift")
