@@ -7,6 +7,7 @@ import os
 import sys
 
 import numpy as np
+import scipy.signal as scipysig
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tzddpc_amd import cplite as cp                      # reference: import cvxpy as cp
@@ -31,13 +32,14 @@ def constraints_callback(u, x):
 def main(total_steps=12, verbose=True):
     A = np.array([[1, 1], [0, 1]]); B = np.array([[0.5], [1]])
     dim_x, dim_u = B.shape
+    sys_ = scipysig.StateSpace(A, B, np.eye(dim_x), np.zeros((dim_x, dim_u)), dt=1)     # reference :37-40
     X0 = Zonotope([-5, -2], 0 * np.eye(dim_x))
     U = Zonotope([0], 1 * np.ones((1, 1)))
     W = Zonotope(np.zeros(dim_x), 0.1 * np.array([[1, 0.5], [0.5, 1]]))
     X = Zonotope([-4, 0], 0.95 * np.diag([5, 2.5]))
     zonotopes = SystemZonotopes(X0, U, X, W)
     W_vertices = W.compute_vertices()
-    data = generate_trajectories(A, B, X0, U, W, 1, 100, np.random.default_rng(25))
+    data = generate_trajectories(sys_, X0, U, W, 1, 100)                                    # reference :59, same call
     x0 = X0.sample().flatten()
 
     tzddpc = TZDDPC(data)

@@ -123,6 +123,56 @@ int tz_abi_version(void);
 const char* tz_last_error(void);
 int tz_device_count(int* count);
 
+/*
+ * K0 -- identification of B data sets on the device (Monte Carlo over data seeds): what TZDDPC.build_zonotopes +
+ * build_zonotopes_theta compute per data set (reference tzddpc/tzddpc.py:67-85, :119-128), in the closed form the Girard order-1
+ * reduce(1) of :126-128 gives (valid when W has more than n (n + m) / (T - 1) generators, i.e. always for the examples' T):
+ *   u : B x T x m, x : B x T x n          input / state data (reference :20-28; row t of x is the state BEFORE input row t acts)
+ *   w_center : n                          centre of W
+ *   K : m x n (k_shared != 0) or B x m x n, may be NULL
+ *   C  : B x n x (n+m)  (out)             centre of Mdata = [A_hat | B_hat]                                   (:83, :163)
+ *   s  : B x (n+m)      (out)             sum_t |pinv([Xm'; Um'])[t, :]|: the boxed generators of Mdata / Mdelta are rad(W) s'
+ *   sK : B x n          (out, NULL if K is)   the same for MdataK = Mdata [I; K]: rad(W) sK'                   (:119)
+ *   CK : B x n x n      (out, NULL if K is)   centre of MdataK = A_hat + B_hat K
+ *   status : B int32    (out)             0, or TZ_NUMERICAL when the data are not persistently exciting (Gram matrix singular)
+ * Gram contractions on v_mfma_f64_4x4x4, one wave per data set.
+ */
+int tz_identify_batch(int device, int32_t B, int32_t T, int32_t n, int32_t m, const double* u, const double* x,
+                      const double* w_center, const double* K, int32_t k_shared,
+                      double* C, double* s, double* sK, double* CK, int32_t* status, int mem);
+
+/*
+ * K1g -- literal stacked-generator tubes (the general path: any generators of MdataK / Mdelta, boxed or dense).
+ * Every generator column of every tube Ze[k] the reference builds by zonotope algebra (tzddpc/tzddpc.py:172-207, :283-324) is
+ * g = m0 + M xi_src with xi_src = e0 (src 0), zeta_j = [xbar_j; v_j] (src 1 + j) or nothing (src -1); the host lists them in the
+ * reference's order (tzddpc_amd/genstack.py), the device streams the list from HBM and evaluates per trajectory
+ *     centre_k,  rad^x_k = sum_g |g|,  rad^u_k = sum_g |K g|        -- Ze[k].interval, (Ze[k] * K).interval of :191-192
+ * (tz_genstack_intervals) or the columns [centre | generators] of one tube, the Z.value of the CVXZonotope solve() returns at
+ * :377 (tz_genstack_values).
+ */
+typedef struct tz_genstack_desc {
+  int32_t n, m, N, nseg;          /* dim_x, dim_u, horizon, number of tubes Ze[0 .. nseg-1] */
+  const int32_t* seg_ptr;         /* nseg + 1: generators of Ze[k] are [seg_ptr[k], seg_ptr[k+1]) */
+  const int32_t* src;             /* G */
+  const double* m0;               /* G x n */
+  const double* M;                /* G x n x (n+m), columns beyond the width of the source zero */
+  const double* c0;               /* nseg x n            centre_k = c0 + cE e0 + sum_j cZ[k][j] zeta_j */
+  const double* cE;               /* nseg x n x n */
+  const double* cZ;               /* nseg x N x n x (n+m), may be NULL (zero: Mdelta has a zero centre, :122-123) */
+  const double* K;                /* m x n */
+} tz_genstack_desc;
+typedef struct tz_genstack tz_genstack;
+int tz_genstack_create(int device, const tz_genstack_desc* desc, tz_genstack** out);
+int tz_genstack_destroy(tz_genstack* g);
+/* e0 : B x n, zeta : B x N x (n+m);  centre, rad_x : B x nseg x n, rad_u : B x nseg x m;  kernel_ms (may be NULL): HIP-event
+ * time of the streaming kernel of this call */
+int tz_genstack_intervals(tz_genstack* g, int32_t B, const double* e0, const double* zeta,
+                          double* centre, double* rad_x, double* rad_u, double* kernel_ms, int mem);
+/* Z : B x n x (1 + Gamma_seg), column 0 the centre, then the generators of Ze[seg] in the reference's order */
+int tz_genstack_values(tz_genstack* g, int32_t seg, int32_t B, const double* e0, const double* zeta, double* Z, int mem);
+/* generators, bytes of the stack streamed per tile of 256 trajectories, chunks (= workgroups per tile) */
+int tz_genstack_info(tz_genstack* g, int64_t* generators, int64_t* stack_bytes, int64_t* chunks);
+
 /* Build-time: upload one problem to `device`.  Stands behind the *result* of
  * TZDDPC.build_problem / build_problem_simplified (reference tzddpc/tzddpc.py:132, :243), i.e. the
  * object `self.problem_full` that solve() later consumes. */

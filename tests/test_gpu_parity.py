@@ -430,3 +430,148 @@ def test_unsupported_sizes_fail_loudly(built):
     ctl, (A, B, zon) = common.gpu_controller("di_n5")
     with pytest.raises(native.NativeError, match="not supported"):
         ctl.build_problem(200, common.loss_di, common.nocons)
+
+
+@pytest.mark.parametrize("sysname", ["di_sim", "di_cc", "pulley", "dim5_w001"])
+def test_device_identification_matches_oracle(built, sysname):
+    """K0 (tz_identify_batch): centre of Mdata, boxed magnitudes of Mdata / Mdelta / MdataK after reduce(1) (reference
+    tzddpc/tzddpc.py:67-85, 119-128) for a batch of data seeds against oracle.harness.identify, <= 1e-10."""
+    from oracle import harness as H
+    from oracle.collapsed import single_entry_abs
+    from tzddpc_amd import native, TZDDPC, Data, Theta
+    from tzddpc_amd.harness import system
+    s = H.system(sysname)
+    n, m = s["B"].shape
+    seeds = [25, 1, 2, 3, 4, 5]
+    us, xs, ids = [], [], []
+    for sd in seeds:
+        u, x = H.generate_trajectories(s["A"], s["B"], s["X0"], s["U"], s["W"], 1, s["T"], np.random.default_rng(sd))
+        us.append(u); xs.append(x); ids.append(H.identify(u, x, s["W"]))
+    Ks = np.stack([i["K"] for i in ids])
+    out = native.identify_batch(0, np.stack(us), np.stack(xs), s["W"].center, K=Ks)
+    assert (out["status"] == 0).all()
+    radW = np.abs(s["W"].generators).sum(axis=1)
+    for b, idn in enumerate(ids):
+        scale = 1 + np.abs(idn["Mdata"].center).max()
+        np.testing.assert_allclose(out["C"][b], idn["Mdata"].center, rtol=0, atol=1e-10 * scale)
+        np.testing.assert_allclose(out["CK"][b], idn["MdataK"].center, rtol=0, atol=1e-10 * scale)
+        np.testing.assert_allclose(np.outer(radW, out["s"][b]), single_entry_abs(idn["Mdelta"]), rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(np.outer(radW, out["sK"][b]), single_entry_abs(idn["MdataK"]), rtol=1e-10, atol=1e-14)
+    # the controller built with device=True solves the same problem as the host-identified one
+    A, B, zon, T = system(sysname)
+    th = Theta(ids[0]["K"], np.zeros_like(A), np.zeros_like(B))
+    host = TZDDPC(Data(us[0], xs[0])); host.build_zonotopes_theta(zon, theta=th)
+    dev = TZDDPC(Data(us[0], xs[0])); dev.build_zonotopes_theta(zon, theta=th, device=True)
+    for name in ("Mdata", "MdataK", "Mdelta"):
+        np.testing.assert_allclose(getattr(dev, name).center, getattr(host, name).center, rtol=0, atol=1e-10 * scale)
+        np.testing.assert_allclose(getattr(dev, name).single_entry_magnitudes(), getattr(host, name).single_entry_magnitudes(), rtol=1e-10, atol=1e-14)
+    if sysname == "di_cc":
+        host.build_problem(10, common.loss_di, common.nocons); dev.build_problem(10, common.loss_di, common.nocons)
+        x0, e0 = common.sample_params(zon, n, 8, seed=3)
+        a, b2 = host.solve_batch(x0, e0), dev.solve_batch(x0, e0)
+        assert (a["status"] == 0).all() and (b2["status"] == 0).all()
+        np.testing.assert_allclose(a["v"][:, 0], b2["v"][:, 0], atol=1e-7)
+        np.testing.assert_allclose(a["cost"], b2["cost"], rtol=1e-8)
+
+
+def _oracle_setup(sysname):
+    from oracle import harness as H
+    s = H.system(sysname)
+    rng = np.random.default_rng(25)
+    u, x = H.generate_trajectories(s["A"], s["B"], s["X0"], s["U"], s["W"], 1, s["T"], rng)
+    return s, u, x, H.identify(u, x, s["W"]), rng
+
+
+@pytest.mark.parametrize("sysname", ["di_sim", "pulley", "dim5_w001"])
+@pytest.mark.parametrize("N,k0", [(3, None), (4, 1), (4, 2)])
+def test_literal_tubes_match_oracle_generator_stacking(built, sysname, N, k0):
+    """K1g (tz_genstack_*): interval hulls of the literal tubes Ze[k] and the columns of Ze[1] from the device against
+    oracle.literal (literal MatrixZonotope * CVXZonotope stacking, reference tzddpc/tzddpc.py:172-207 / :283-324) at random
+    decision vectors: same generator counts (24, 64, 343 ...), same column order, values to 1e-12."""
+    from oracle import harness as H, literal as L
+    from tzddpc_amd import TZDDPC, Data, Theta
+    from tzddpc_amd.harness import system
+    if sysname.startswith("dim5") and (N, k0) != (3, None):
+        pytest.skip("literal stacking of the 5-dim system at N = 4 has 1e5 generators (minutes in the numpy oracle)")
+    s, u, x, idn, rng = _oracle_setup(sysname)
+    A, B, zon, T = system(sysname)
+    n, m = B.shape
+    ctl = TZDDPC(Data(u, x))
+    ctl.build_zonotopes_theta(zon, theta=Theta(idn["K"], np.zeros_like(A), np.zeros_like(B)))
+    loss = {"di_sim": common.loss_di, "pulley": common.loss_pulley, "dim5_w001": common.loss_dim5}[sysname]
+    oloss = {"di_sim": H.loss_di, "pulley": H.loss_pulley, "dim5_w001": H.loss_dim5}[sysname]
+    cons = common.cons_dim5 if sysname.startswith("dim5") else common.nocons
+    ctl.horizon, ctl.k0 = N, k0                                  # literal_tubes only needs the zonotopes, the gain and (N, k0)
+    Bn = 5
+    e0 = 0.02 * rng.standard_normal((Bn, n)); xb = rng.standard_normal((Bn, N + 1, n)); v = rng.standard_normal((Bn, N, m))
+    out = ctl.literal_tubes(e0, xb, v)
+    for b in range(Bn):
+        lp = L.build_literal(idn["A"], idn["B"], idn["MdataK"], idn["Mdelta"], idn["K"], s["W"], s["X"], s["U"], N, e0[b], xb[b, 0], oloss, None, k0)
+        xi = np.concatenate([xb[b].reshape(-1), v[b].reshape(-1)])
+        for k, Zl in enumerate(lp.Ze):
+            Zn = Zl.value(xi)
+            sc = 1 + np.abs(Zn.generators).sum()
+            np.testing.assert_allclose(out["center"][b, k], Zn.center, rtol=0, atol=1e-12 * sc)
+            np.testing.assert_allclose(out["rad_x"][b, k], np.abs(Zn.generators).sum(axis=1), rtol=0, atol=1e-12 * sc)
+            np.testing.assert_allclose(out["rad_u"][b, k], np.abs(idn["K"] @ Zn.generators).sum(axis=1), rtol=0, atol=1e-12 * sc)
+    # Ze[1] as solve() returns it: [centre | generators] in the reference's column order
+    Z1 = ctl.ze1_batch(xb[:, 0], e0, v[:, 0])
+    for b in range(Bn):
+        lp = L.build_literal(idn["A"], idn["B"], idn["MdataK"], idn["Mdelta"], idn["K"], s["W"], s["X"], s["U"], max(N, 2), e0[b], xb[b, 0], oloss, None, None)
+        xi = np.zeros(lp.nxi); xi[:n] = xb[b, 0]; xi[(max(N, 2) + 1) * n:(max(N, 2) + 1) * n + m] = v[b, 0]
+        Zn = lp.Ze[1].value(xi)
+        assert Z1.shape[2] == 1 + Zn.generators.shape[1]
+        np.testing.assert_allclose(Z1[b, :, 0], Zn.center, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(Z1[b, :, 1:], Zn.generators, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(Z1[b], ctl._ze1_host(xb[b, 0], e0[b], v[b, 0]), rtol=0, atol=1e-13)
+
+
+def test_literal_tubes_dense_generators_and_collapsed_where_exact(built):
+    """(i) DENSE matrix-zonotope generators (Girard order 2 instead of the boxes of reduce(1)): the collapsed solver path refuses
+    them (StructureError), the literal path evaluates them -- against oracle.literal.  (ii) Boxed generators at N = 20, k0 = 1
+    (4577 absolute-value terms): the literal hulls equal the collapsed radii of the oracle (exact where the collapse applies)."""
+    from oracle import collapsed as OC, harness as H, literal as L
+    from oracle.zonolite import MatrixZonotope as OMZ
+    from tzddpc_amd import TZDDPC, Data, Theta
+    from tzddpc_amd.builder import StructureError
+    from tzddpc_amd.harness import system
+    from tzddpc_amd.zonotope import MatrixZonotope
+    s, u, x, idn, rng = _oracle_setup("di_cc")
+    A, B, zon, T = system("di_cc")
+    n, m = B.shape
+    ctl = TZDDPC(Data(u, x))
+    ctl.build_zonotopes_theta(zon, theta=Theta(idn["K"], np.zeros_like(A), np.zeros_like(B)))
+    # (i) order-2 reductions of the raw matrix zonotopes: 2 n^2 / 2 n (n+m) generators, the kept ones dense
+    dK, dD = idn["MdataK_raw"].reduce(2), idn["Mdelta_raw"].reduce(2)
+    assert np.count_nonzero(dK.generators.reshape(dK.num_generators, -1), axis=1).max() > 1
+    boxedK, boxedD = ctl.MdataK, ctl.Mdelta
+    ctl.MdataK, ctl.Mdelta = MatrixZonotope(dK.center, dK.generators), MatrixZonotope(dD.center, dD.generators)
+    with pytest.raises(StructureError):
+        ctl.build_problem(3, common.loss_di, common.nocons)
+    N = 3
+    ctl.horizon, ctl.k0 = N, None; ctl._gs_full = None
+    Bn = 4
+    e0 = 0.02 * rng.standard_normal((Bn, n)); xb = rng.standard_normal((Bn, N + 1, n)); v = rng.standard_normal((Bn, N, m))
+    out = ctl.literal_tubes(e0, xb, v)
+    for b in range(Bn):
+        lp = L.build_literal(idn["A"], idn["B"], dK, dD, idn["K"], s["W"], s["X"], s["U"], N, e0[b], xb[b, 0], H.loss_di, None, None)
+        xi = np.concatenate([xb[b].reshape(-1), v[b].reshape(-1)])
+        for k, Zl in enumerate(lp.Ze):
+            Zn = Zl.value(xi)
+            np.testing.assert_allclose(out["rad_x"][b, k], np.abs(Zn.generators).sum(axis=1), rtol=0, atol=1e-12 * (1 + np.abs(Zn.generators).sum()))
+            np.testing.assert_allclose(out["center"][b, k], Zn.center, rtol=0, atol=1e-12)
+    # (ii) boxed generators, simplified problem at its real size
+    ctl.MdataK, ctl.Mdelta = boxedK, boxedD
+    N, k0 = 20, 1
+    ctl.horizon, ctl.k0 = N, k0; ctl._gs_full[1].close(); ctl._gs_full = None
+    Bn = 64
+    e0 = 0.02 * rng.standard_normal((Bn, n)); xb = rng.standard_normal((Bn, N + 1, n)); v = rng.standard_normal((Bn, N, m))
+    out = ctl.literal_tubes(e0, xb, v)
+    assert ctl._gs_full[1].num_generators.max() == 264                   # SURVEY.md a-3: Gamma <= 264 for the double integrator at k0 = 1
+    for b in (0, 17, 63):
+        cq = OC.build_collapsed(idn["A"], idn["B"], idn["MdataK"], idn["Mdelta"], idn["K"], s["W"], s["X"], s["U"], N, e0[b], xb[b, 0], H.loss_di, None, k0)
+        cr = OC.collapsed_radii(cq, np.concatenate([xb[b].reshape(-1), v[b].reshape(-1)]))
+        for k, (cc, rx, ru) in enumerate(cr):
+            np.testing.assert_allclose(out["center"][b, k], cc, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(out["rad_x"][b, k], rx, rtol=0, atol=1e-11 * (1 + rx.max()))
+            np.testing.assert_allclose(out["rad_u"][b, k], ru, rtol=0, atol=1e-11 * (1 + ru.max()))

@@ -188,6 +188,8 @@ struct FuseParams {
 };
 
 #include "tz_ipm.hip.h"
+#include "tz_identify.hip.h"
+#include "tz_genstack.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // Finish: one wave per trajectory.

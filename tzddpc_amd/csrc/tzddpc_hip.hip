@@ -367,6 +367,198 @@ int tz_device_count(int* count) {
   return TZ_OK;
 }
 
+int tz_identify_batch(int device, int32_t B, int32_t T, int32_t n, int32_t m, const double* u, const double* x,
+                      const double* w_center, const double* K, int32_t k_shared,
+                      double* C, double* s, double* sK, double* CK, int32_t* status, int mem) {
+  if (!u || !x || !w_center || !C || !s || !status) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  if (B <= 0 || T < 2) TZ_FAIL(TZ_ERR_INVALID, "B must be positive and T at least 2");
+  if (n < 1 || n > TZ_NMAX || m < 1 || m > TZ_MMAX) TZ_FAIL(TZ_ERR_UNSUPPORTED, "dim_x must be 1..%d and dim_u 1..%d", TZ_NMAX, TZ_MMAX);
+  if (K && (!sK || !CK)) TZ_FAIL(TZ_ERR_INVALID, "sK and CK are required when K is given");
+  if (mem != TZ_MEM_HOST && mem != TZ_MEM_DEVICE) TZ_FAIL(TZ_ERR_INVALID, "mem must be TZ_MEM_HOST or TZ_MEM_DEVICE");
+  int ndev = 0;
+  TZ_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) TZ_FAIL(TZ_ERR_HIP, "no HIP device visible: the TZDDPC hot path has no CPU fallback");
+  if (device < 0 || device >= ndev) TZ_FAIL(TZ_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+  TZ_HIP(hipSetDevice(device));
+  const int p = n + m;
+  const size_t b = (size_t)B;
+  IdentifyParams q{B, T, n, m, u, x, w_center, K, k_shared ? 1 : 0, C, s, K ? sK : nullptr, K ? CK : nullptr, status};
+  DevBuf<double> du, dx, dw, dK, dC, ds, dsK, dCK; DevBuf<int> dst;
+  if (mem == TZ_MEM_HOST) {
+    TZ_HIP(du.upload(u, b * T * m)); TZ_HIP(dx.upload(x, b * T * n)); TZ_HIP(dw.upload(w_center, (size_t)n));
+    if (K) TZ_HIP(dK.upload(K, (k_shared ? 1 : b) * m * n));
+    TZ_HIP(dC.alloc(b * n * p)); TZ_HIP(ds.alloc(b * p)); TZ_HIP(dsK.alloc(b * n)); TZ_HIP(dCK.alloc(b * n * n)); TZ_HIP(dst.alloc(b));
+    q.u = du.p; q.x = dx.p; q.wc = dw.p; q.K = K ? dK.p : nullptr; q.C = dC.p; q.s = ds.p; q.sK = K ? dsK.p : nullptr; q.CK = K ? dCK.p : nullptr; q.status = dst.p;
+  }
+  hipLaunchKernelGGL(tz_identify_kernel, dim3(B), dim3(64), 0, 0, q);
+  TZ_HIP(hipGetLastError());
+  if (mem == TZ_MEM_HOST) {
+    TZ_HIP(hipMemcpy(C, dC.p, b * n * p * sizeof(double), hipMemcpyDeviceToHost));
+    TZ_HIP(hipMemcpy(s, ds.p, b * p * sizeof(double), hipMemcpyDeviceToHost));
+    if (K) { TZ_HIP(hipMemcpy(sK, dsK.p, b * n * sizeof(double), hipMemcpyDeviceToHost)); TZ_HIP(hipMemcpy(CK, dCK.p, b * n * n * sizeof(double), hipMemcpyDeviceToHost)); }
+    TZ_HIP(hipMemcpy(status, dst.p, b * sizeof(int), hipMemcpyDeviceToHost));
+  }
+  return TZ_OK;
+}
+
+struct tz_genstack {
+  int device = 0, n = 0, m = 0, N = 0, nseg = 0, rec = 0, nchunk = 0;
+  int64_t G = 0;
+  std::vector<int> seg_ptr;                 // literal order
+  DevBuf<double> recs_sorted, recs_lit, c0, cE, cZ, K, partial, in_e0, in_zeta, o_c, o_rx, o_ru, o_Z;
+  DevBuf<int> src_lit, seg_chunk_ptr;
+  DevBuf<GsChunk> chunks;
+  int Bcap = 0;
+  bool have_cZ = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+int tz_genstack_create(int device, const tz_genstack_desc* d, tz_genstack** out) {
+  if (!d || !out || !d->seg_ptr || !d->src || !d->m0 || !d->M || !d->c0 || !d->cE || !d->K) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  if (d->n < 1 || d->n > TZ_NMAX || d->m < 1 || d->m > TZ_MMAX) TZ_FAIL(TZ_ERR_UNSUPPORTED, "dim_x must be 1..%d and dim_u 1..%d", TZ_NMAX, TZ_MMAX);
+  if (d->N < 1 || d->nseg < 1) TZ_FAIL(TZ_ERR_INVALID, "N and nseg must be positive");
+  int ndev = 0;
+  TZ_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) TZ_FAIL(TZ_ERR_HIP, "no HIP device visible: the TZDDPC hot path has no CPU fallback");
+  if (device < 0 || device >= ndev) TZ_FAIL(TZ_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+  TZ_HIP(hipSetDevice(device));
+  std::unique_ptr<tz_genstack> g(new tz_genstack());
+  const int n = d->n, m = d->m, p = n + m, rec = n * (1 + p);
+  g->device = device; g->n = n; g->m = m; g->N = d->N; g->nseg = d->nseg; g->rec = rec;
+  g->seg_ptr.assign(d->seg_ptr, d->seg_ptr + d->nseg + 1);
+  const int64_t G = g->seg_ptr[d->nseg];
+  g->G = G;
+  for (int64_t i = 0; i < G; ++i) if (d->src[i] < -1 || d->src[i] > d->N) TZ_FAIL(TZ_ERR_INVALID, "src[%lld] out of range", (long long)i);
+  // records [m0 | M]: literal order (tz_genstack_values) and sorted by (tube, source) + cut into chunks (tz_genstack_intervals)
+  std::vector<double> lit((size_t)std::max<int64_t>(G, 1) * rec, 0.0), srt(lit.size(), 0.0);
+  auto fill = [&](double* dst, int64_t gi) {
+    for (int i = 0; i < n; ++i) { dst[i] = d->m0[(size_t)gi * n + i]; for (int c = 0; c < p; ++c) dst[n + i * p + c] = d->M[((size_t)gi * n + i) * p + c]; }
+  };
+  for (int64_t gi = 0; gi < G; ++gi) fill(&lit[(size_t)gi * rec], gi);
+  std::vector<GsChunk> chunks; std::vector<int> scp((size_t)d->nseg + 1, 0);
+  int64_t pos = 0;
+  for (int k = 0; k < d->nseg; ++k) {
+    std::vector<int64_t> idx;
+    for (int64_t gi = g->seg_ptr[k]; gi < g->seg_ptr[k + 1]; ++gi) idx.push_back(gi);
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b2) { return d->src[a] < d->src[b2]; });
+    size_t a = 0;
+    while (a < idx.size()) {
+      size_t b2 = a;
+      while (b2 < idx.size() && d->src[idx[b2]] == d->src[idx[a]] && b2 - a < TZ_GS_CHUNK) ++b2;
+      chunks.push_back(GsChunk{k, d->src[idx[a]], (int)pos, (int)(pos + (int64_t)(b2 - a))});
+      for (size_t e = a; e < b2; ++e) fill(&srt[(size_t)pos++ * rec], idx[e]);
+      a = b2;
+    }
+    scp[k + 1] = (int)chunks.size();
+  }
+  g->nchunk = (int)chunks.size();
+  TZ_HIP(g->recs_lit.upload(lit)); TZ_HIP(g->recs_sorted.upload(srt));
+  TZ_HIP(g->src_lit.upload(d->src, (size_t)std::max<int64_t>(G, 1)));
+  if (chunks.empty()) chunks.push_back(GsChunk{0, -1, 0, 0});
+  TZ_HIP(g->chunks.upload(chunks)); TZ_HIP(g->seg_chunk_ptr.upload(scp));
+  TZ_HIP(g->c0.upload(d->c0, (size_t)d->nseg * n)); TZ_HIP(g->cE.upload(d->cE, (size_t)d->nseg * n * n));
+  if (d->cZ) {
+    const size_t cnt = (size_t)d->nseg * d->N * n * p;
+    for (size_t i = 0; i < cnt && !g->have_cZ; ++i) if (d->cZ[i] != 0.0) g->have_cZ = true;
+    if (g->have_cZ) TZ_HIP(g->cZ.upload(d->cZ, cnt));
+  }
+  TZ_HIP(g->K.upload(d->K, (size_t)m * n));
+  TZ_HIP(hipEventCreate(&g->ev0)); TZ_HIP(hipEventCreate(&g->ev1));
+  *out = g.release();
+  return TZ_OK;
+}
+
+int tz_genstack_destroy(tz_genstack* g) {
+  if (!g) return TZ_OK;
+  (void)hipSetDevice(g->device);
+  (void)hipDeviceSynchronize();
+  if (g->ev0) (void)hipEventDestroy(g->ev0);
+  if (g->ev1) (void)hipEventDestroy(g->ev1);
+  delete g;
+  return TZ_OK;
+}
+
+int tz_genstack_info(tz_genstack* g, int64_t* generators, int64_t* stack_bytes, int64_t* chunks) {
+  if (!g) TZ_FAIL(TZ_ERR_INVALID, "null handle");
+  if (generators) *generators = g->G;
+  if (stack_bytes) *stack_bytes = g->G * g->rec * (int64_t)sizeof(double);
+  if (chunks) *chunks = g->nchunk;
+  return TZ_OK;
+}
+
+namespace {
+int gs_inputs(tz_genstack* g, int B, const double* e0, const double* zeta, int mem, const double** de0, const double** dz) {
+  const size_t p = g->n + g->m;
+  if (mem == TZ_MEM_DEVICE) { *de0 = e0; *dz = zeta; return TZ_OK; }
+  if (mem != TZ_MEM_HOST) TZ_FAIL(TZ_ERR_INVALID, "mem must be TZ_MEM_HOST or TZ_MEM_DEVICE");
+  TZ_HIP(g->in_e0.upload(e0, (size_t)B * g->n)); TZ_HIP(g->in_zeta.upload(zeta, (size_t)B * g->N * p));
+  *de0 = g->in_e0.p; *dz = g->in_zeta.p;
+  return TZ_OK;
+}
+}  // namespace
+
+int tz_genstack_intervals(tz_genstack* g, int32_t B, const double* e0, const double* zeta,
+                          double* centre, double* rad_x, double* rad_u, double* kernel_ms, int mem) {
+  if (!g || !e0 || !zeta || !centre || !rad_x || !rad_u) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  if (B <= 0) TZ_FAIL(TZ_ERR_INVALID, "batch size must be positive");
+  TZ_HIP(hipSetDevice(g->device));
+  const int n = g->n, m = g->m, p = n + m;
+  const double *de0 = nullptr, *dz = nullptr;
+  int rc = gs_inputs(g, B, e0, zeta, mem, &de0, &dz);
+  if (rc) return rc;
+  if (B > g->Bcap) { TZ_HIP(g->partial.alloc((size_t)g->nchunk * B * p)); g->Bcap = B; }
+  double *dc = centre, *drx = rad_x, *dru = rad_u;
+  if (mem == TZ_MEM_HOST) {
+    TZ_HIP(g->o_c.alloc((size_t)B * g->nseg * n)); TZ_HIP(g->o_rx.alloc((size_t)B * g->nseg * n)); TZ_HIP(g->o_ru.alloc((size_t)B * g->nseg * m));
+    dc = g->o_c.p; drx = g->o_rx.p; dru = g->o_ru.p;
+  }
+  GenstackParams q{B, n, m, g->N, g->nseg, g->nchunk, g->rec, g->recs_sorted.p, g->chunks.p, g->K.p, de0, dz, g->partial.p};
+  const dim3 grid((unsigned)g->nchunk, (unsigned)((B + 255) / 256));
+  TZ_HIP(hipEventRecord(g->ev0, 0));
+  if (n == 2 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<2, 1>), grid, dim3(256), 0, 0, q);
+  else if (n == 4 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<4, 1>), grid, dim3(256), 0, 0, q);
+  else if (n == 5 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<5, 1>), grid, dim3(256), 0, 0, q);
+  else hipLaunchKernelGGL((tz_genstack_kernel<0, 0>), grid, dim3(256), 0, 0, q);
+  TZ_HIP(hipEventRecord(g->ev1, 0));
+  GsReduceParams r{B, n, m, g->N, g->nseg, g->seg_chunk_ptr.p, g->partial.p, g->c0.p, g->cE.p, g->have_cZ ? g->cZ.p : nullptr, de0, dz, dc, drx, dru};
+  const size_t total = (size_t)B * g->nseg * p;
+  hipLaunchKernelGGL(tz_genstack_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, r);
+  TZ_HIP(hipGetLastError());
+  if (mem == TZ_MEM_HOST) {
+    TZ_HIP(hipMemcpy(centre, dc, (size_t)B * g->nseg * n * sizeof(double), hipMemcpyDeviceToHost));
+    TZ_HIP(hipMemcpy(rad_x, drx, (size_t)B * g->nseg * n * sizeof(double), hipMemcpyDeviceToHost));
+    TZ_HIP(hipMemcpy(rad_u, dru, (size_t)B * g->nseg * m * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (kernel_ms) {
+    TZ_HIP(hipEventSynchronize(g->ev1));
+    float ms = 0.f;
+    TZ_HIP(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+    *kernel_ms = ms;
+  }
+  return TZ_OK;
+}
+
+int tz_genstack_values(tz_genstack* g, int32_t seg, int32_t B, const double* e0, const double* zeta, double* Z, int mem) {
+  if (!g || !e0 || !zeta || !Z) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  if (B <= 0 || seg < 0 || seg >= g->nseg) TZ_FAIL(TZ_ERR_INVALID, "bad batch size or tube index");
+  TZ_HIP(hipSetDevice(g->device));
+  const int n = g->n, m = g->m, p = n + m;
+  const double *de0 = nullptr, *dz = nullptr;
+  int rc = gs_inputs(g, B, e0, zeta, mem, &de0, &dz);
+  if (rc) return rc;
+  const int ngen = g->seg_ptr[seg + 1] - g->seg_ptr[seg];
+  const size_t cnt = (size_t)B * n * (1 + ngen);
+  double* dZ = Z;
+  if (mem == TZ_MEM_HOST) { TZ_HIP(g->o_Z.alloc(cnt)); dZ = g->o_Z.p; }
+  GsValuesParams q{B, n, m, g->N, seg, ngen, g->rec, g->recs_lit.p + (size_t)g->seg_ptr[seg] * g->rec, g->src_lit.p + g->seg_ptr[seg],
+                   g->c0.p + (size_t)seg * n, g->cE.p + (size_t)seg * n * n, g->have_cZ ? g->cZ.p + (size_t)seg * g->N * n * p : nullptr, de0, dz, dZ};
+  const size_t total = (size_t)B * (1 + ngen);
+  hipLaunchKernelGGL(tz_genstack_values_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, q);
+  TZ_HIP(hipGetLastError());
+  if (mem == TZ_MEM_HOST) TZ_HIP(hipMemcpy(Z, dZ, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  return TZ_OK;
+}
+
 int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (!d || !out) TZ_FAIL(TZ_ERR_INVALID, "null argument");
   if (d->abi_version != TZ_ABI_VERSION) TZ_FAIL(TZ_ERR_INVALID, "abi_version %d != %d", d->abi_version, TZ_ABI_VERSION);

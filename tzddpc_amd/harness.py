@@ -15,9 +15,22 @@ from .objects import Data, SystemZonotopes
 from .zonotope import Zonotope
 
 
-def generate_trajectories(A, B, X0: Zonotope, U: Zonotope, W: Zonotope, num_trajectories: int, num_steps: int,
-                          rng: Optional[np.random.Generator] = None) -> Data:
-    rng = np.random.default_rng() if rng is None else rng
+def generate_trajectories(*args, rng: Optional[np.random.Generator] = None) -> Data:
+    """Two call forms:
+
+    ``generate_trajectories(sys, X0, U, W, num_trajectories, num_steps)`` -- the reference's (``examples/utils.py:6-12``): ``sys``
+    is anything with ``.A`` and ``.B`` (``scipy.signal.StateSpace``); random numbers from numpy's global state, as there;
+    ``generate_trajectories(A, B, X0, U, W, num_trajectories, num_steps[, rng])`` -- plant matrices and an explicit generator.
+    """
+    if len(args) >= 6 and hasattr(args[0], "A") and hasattr(args[0], "B"):
+        sysd, X0, U, W, num_trajectories, num_steps = args[:6]
+        A, B = np.asarray(sysd.A, float), np.asarray(sysd.B, float)
+        rest = args[6:]
+    else:
+        A, B, X0, U, W, num_trajectories, num_steps = args[:7]
+        rest = args[7:]
+    if rest:
+        rng = rest[0]
     A = np.asarray(A, float); B = np.asarray(B, float)
     n, m = B.shape
     total = num_steps * num_trajectories
@@ -27,7 +40,8 @@ def generate_trajectories(A, B, X0: Zonotope, U: Zonotope, W: Zonotope, num_traj
     for j in range(num_trajectories):
         X[j, 0] = X0.sample(1, rng)[0]
         for i in range(1, num_steps):
-            X[j, i] = A @ X[j, i - 1] + np.squeeze(B * u[j, i - 1]) + Wv[rng.integers(len(Wv))]
+            pick = np.random.choice(len(Wv)) if rng is None else rng.integers(len(Wv))
+            X[j, i] = A @ X[j, i - 1] + np.squeeze(B * u[j, i - 1]) + Wv[pick]
             Y[j, i] = X[j, i]
     return Data(u.reshape(total, m), Y.reshape(total, n))
 

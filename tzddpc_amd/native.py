@@ -47,6 +47,11 @@ class ProblemDesc(C.Structure):
     ]
 
 
+class GenstackDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("N", C.c_int32), ("nseg", C.c_int32), ("seg_ptr", _ip), ("src", _ip),
+                ("m0", _dp), ("M", _dp), ("c0", _dp), ("cE", _dp), ("cZ", _dp), ("K", _dp)]
+
+
 _lib = None
 
 
@@ -84,6 +89,15 @@ def lib():
     L.tz_simulate_batch.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.tz_mpc_step.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.tz_mpc_run.argtypes = [vp, C.c_int32, C.c_int32] + [vp] * 9
+    L.tz_identify_batch.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [vp] * 4 + [C.c_int32] + [vp] * 5 + [C.c_int]
+    L.tz_identify_batch.restype = C.c_int
+    L.tz_genstack_create.argtypes = [C.c_int, C.POINTER(GenstackDesc), C.POINTER(vp)]
+    L.tz_genstack_destroy.argtypes = [vp]
+    L.tz_genstack_intervals.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_double), C.c_int]
+    L.tz_genstack_values.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_int]
+    L.tz_genstack_info.argtypes = [vp] + [C.POINTER(C.c_int64)] * 3
+    for nm in ("tz_genstack_create", "tz_genstack_destroy", "tz_genstack_intervals", "tz_genstack_values", "tz_genstack_info"):
+        getattr(L, nm).restype = C.c_int
     L.tz_problem_reset_warm.argtypes = [vp]
     L.tz_problem_set_warm_shift.argtypes = [vp, C.c_int32]
     L.tz_timing_enable.argtypes = [vp, C.c_int]
@@ -104,7 +118,8 @@ def lib():
 EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy",
                     "tz_problem_set_stream", "tz_problem_sync", "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run",
                     "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch",
-                    "tz_problem_set_warm_shift", "tz_problem_reset_warm")
+                    "tz_problem_set_warm_shift", "tz_problem_reset_warm", "tz_identify_batch",
+                    "tz_genstack_create", "tz_genstack_destroy", "tz_genstack_intervals", "tz_genstack_values", "tz_genstack_info")
 
 
 def check(rc: int, what: str):
@@ -117,6 +132,31 @@ def device_count() -> int:
     n = C.c_int(0)
     check(lib().tz_device_count(C.byref(n)), "tz_device_count")
     return n.value
+
+
+def identify_batch(device: int, u: np.ndarray, x: np.ndarray, w_center: np.ndarray, K: Optional[np.ndarray] = None):
+    """K0 (``tz_identify_batch``): u (B, T, m), x (B, T, n) -> dict(C (B, n, n+m), s (B, n+m)[, sK (B, n), CK (B, n, n)], status)."""
+    u = np.ascontiguousarray(u, dtype=np.float64); x = np.ascontiguousarray(x, dtype=np.float64)
+    if u.ndim == 2:
+        u = u[None]; x = x[None]
+    B, T, m = u.shape
+    n = x.shape[2]
+    wc = np.ascontiguousarray(w_center, dtype=np.float64).reshape(n)
+    Cc = np.empty((B, n, n + m)); s = np.empty((B, n + m)); status = np.empty(B, dtype=np.int32)
+    sK = CK = Kc = None
+    shared = 0
+    if K is not None:
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        shared = 1 if Kc.ndim == 2 else 0
+        Kc = Kc.reshape((m, n) if shared else (B, m, n))
+        sK = np.empty((B, n)); CK = np.empty((B, n, n))
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    check(lib().tz_identify_batch(int(device), B, T, n, m, vp(u), vp(x), vp(wc), vp(Kc), shared, vp(Cc), vp(s), vp(sK), vp(CK), vp(status),
+                                  TZ_MEM_HOST), "tz_identify_batch")
+    out = dict(C=Cc, s=s, status=status)
+    if K is not None:
+        out.update(sK=sK, CK=CK)
+    return out
 
 
 def _f64(a):
@@ -288,3 +328,71 @@ class Problem:
         out = np.empty(cap)
         n = check(lib().tz_debug_fetch(self._h, int(b), int(what), out.ctypes.data_as(C.c_void_p), cap), "tz_debug_fetch")
         return out[:n].copy()
+
+
+class GenStack:
+    """Owner of one ``tz_genstack`` handle: the literal stacked-generator tubes of a problem on the device (kernel K1g)."""
+
+    def __init__(self, device: int, st):
+        d = GenstackDesc()
+        keep = []
+        d.n, d.m, d.N, d.nseg = int(st.n), int(st.m), int(st.N), int(st.nseg)
+        sp = _i32(st.seg_ptr); sr = _i32(st.src if st.src.size else np.zeros(1)); keep += [sp, sr]
+        d.seg_ptr = _ptr(sp, _ip); d.src = _ptr(sr, _ip)
+        for name in ("m0", "M", "c0", "cE", "K"):
+            a = _f64(getattr(st, name))
+            if a.size == 0:
+                a = np.zeros(1)
+            keep.append(a); setattr(d, name, _ptr(a, _dp))
+        if np.any(st.cZ):
+            a = _f64(st.cZ); keep.append(a); d.cZ = _ptr(a, _dp)
+        self.n, self.m, self.N, self.nseg = d.n, d.m, d.N, d.nseg
+        self.num_generators = np.diff(np.asarray(st.seg_ptr)).astype(np.int64)
+        h = C.c_void_p()
+        check(lib().tz_genstack_create(int(device), C.byref(d), C.byref(h)), "tz_genstack_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tz_genstack_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _inputs(self, e0, zeta):
+        e0 = _f64(e0).reshape(-1, self.n); B = e0.shape[0]
+        zeta = _f64(zeta).reshape(B, self.N, self.n + self.m)
+        return e0, zeta, B
+
+    def intervals(self, e0, zeta, want_ms: bool = False):
+        """(centre (B, nseg, n), rad_x (B, nseg, n), rad_u (B, nseg, m)) of Ze[k] and K Ze[k] for every trajectory."""
+        e0, zeta, B = self._inputs(e0, zeta)
+        c = np.empty((B, self.nseg, self.n)); rx = np.empty((B, self.nseg, self.n)); ru = np.empty((B, self.nseg, self.m))
+        ms = C.c_double(0.0)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(lib().tz_genstack_intervals(self._h, B, vp(e0), vp(zeta), vp(c), vp(rx), vp(ru), C.byref(ms) if want_ms else None, TZ_MEM_HOST),
+              "tz_genstack_intervals")
+        return (c, rx, ru, ms.value) if want_ms else (c, rx, ru)
+
+    def intervals_ptr(self, B, e0, zeta, centre, rad_x, rad_u):
+        """Device pointers; returns the HIP-event time of the streaming kernel in ms."""
+        ms = C.c_double(0.0)
+        check(lib().tz_genstack_intervals(self._h, int(B), e0, zeta, centre, rad_x, rad_u, C.byref(ms), TZ_MEM_DEVICE), "tz_genstack_intervals")
+        return ms.value
+
+    def values(self, seg: int, e0, zeta):
+        """[centre | generators] of Ze[seg] in the reference's column order: (B, n, 1 + Gamma_seg)."""
+        e0, zeta, B = self._inputs(e0, zeta)
+        Z = np.empty((B, self.n, 1 + int(self.num_generators[seg])))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(lib().tz_genstack_values(self._h, int(seg), B, vp(e0), vp(zeta), vp(Z), TZ_MEM_HOST), "tz_genstack_values")
+        return Z
+
+    def info(self):
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().tz_genstack_info(self._h, C.byref(a), C.byref(b), C.byref(c)), "tz_genstack_info")
+        return dict(generators=a.value, stack_bytes=b.value, chunks=c.value)

@@ -20,7 +20,7 @@ from . import native
 from .builder import ParametricQP, StructureError, build_parametric_qp
 from .gain import compute_theta as _compute_theta
 from .objects import Data, DataDrivenDataset, SystemZonotopes, Theta
-from .zonotope import MatrixZonotope, Zonotope, compute_LTI_matrix_zonotope, concatenate_zonotope
+from .zonotope import MatrixZonotope, Zonotope, boxed_matrix_zonotope, compute_LTI_matrix_zonotope, concatenate_zonotope
 
 
 class _Value:
@@ -109,6 +109,13 @@ class TZDDPC(object):
         if getattr(self, "_native", None) is not None:
             self._native.close()
         self._native = None
+        for name in ("_gs_ze1",):
+            if getattr(self, name, None) is not None:
+                getattr(self, name).close()
+            setattr(self, name, None)
+        if getattr(self, "_gs_full", None) is not None:
+            self._gs_full[1].close()
+        self._gs_full = None
 
     # ---- reference :67-85 ------------------------------------------------------------------------
     def build_zonotopes(self, zonotopes: SystemZonotopes):
@@ -133,9 +140,12 @@ class TZDDPC(object):
     # ---- reference :95-130 -----------------------------------------------------------------------
     def build_zonotopes_theta(self, zonotopes: SystemZonotopes, tol: float = 1e-5, num_max_iterations: int = 20,
                               num_initial_points: int = 10, theta: Optional[Theta] = None,
-                              K: Optional[np.ndarray] = None) -> Tuple[Theta, MatrixZonotope]:
+                              K: Optional[np.ndarray] = None, device: bool = False) -> Tuple[Theta, MatrixZonotope]:
         """As the reference, plus ``theta=`` / ``K=`` to supply the gain as a fixture (the reference's
-        LMI + DCCP/MOSEK synthesis, ``tzddpc/utils.py:60-103``, is out of scope; default is LQR)."""
+        LMI + DCCP/MOSEK synthesis, ``tzddpc/utils.py:60-103``, is out of scope; default is LQR) and ``device=True``:
+        the identification (Gram / pinv contraction, boxed magnitudes) runs on the GPU (``tz_identify_batch``, kernel K0)."""
+        if device:
+            return self._build_zonotopes_theta_device(zonotopes, tol, num_max_iterations, num_initial_points, theta, K)
         self.build_zonotopes(zonotopes)
         if theta is not None:
             self.theta = Theta(np.atleast_2d(np.asarray(theta.K, float)), theta.deltaA, theta.deltaB)
@@ -147,6 +157,36 @@ class TZDDPC(object):
         self.Mdata = self.Mdata.reduce(1)                                                   # :126-128
         self.MdataK = self.MdataK.reduce(1)
         self.Mdelta = self.Mdelta.reduce(1)
+        self._drop_native()
+        return self.theta, self.Mdata
+
+    def _build_zonotopes_theta_device(self, zonotopes, tol, num_max_iterations, num_initial_points, theta, K):
+        """Reference ``:67-85, :95-130`` with the numeric part on the device: centre of Mdata and the boxed generator magnitudes
+        rad(W) s' (Mdata, Mdelta) and rad(W) sK' (MdataK) come out of ``tz_identify_batch`` in the closed form of ``reduce(1)``."""
+        X0, W, X = zonotopes.X0, zonotopes.W, zonotopes.X
+        assert X0.dimension == W.dimension and X0.dimension == self.dim_x and X.dimension == X0.dimension, \
+            "The zonotopes do not have the correct dimension"
+        n, m = self.dim_x, self.dim_u
+        if W.num_generators * (self.num_samples - 1) <= n * (n + m):
+            raise StructureError("too few samples for reduce(1) to box the generators (reference tzddpc/tzddpc.py:126-128): "
+                                 "the closed form of the device identification does not apply")
+        self.optimization_problem = None
+        self.zonotopes = zonotopes
+        data = self.dataset.original_data
+        u, x = np.asarray(data.u, float), np.asarray(data.x, float)
+        radW = np.abs(W.generators).sum(axis=1)
+        first = native.identify_batch(self.device, u, x, W.center)
+        if first["status"][0] != 0:
+            raise Exception("identification failed: the data are not persistently exciting")
+        Cm, s = first["C"][0], first["s"][0]
+        self.Mdata = boxed_matrix_zonotope(Cm, np.outer(radW, s))                        # :83 then :126
+        if theta is not None:
+            self.theta = Theta(np.atleast_2d(np.asarray(theta.K, float)), theta.deltaA, theta.deltaB)
+        else:
+            self.compute_theta(tol, num_max_iterations, num_initial_points, K=K)
+        second = native.identify_batch(self.device, u, x, W.center, K=self.theta.K)
+        self.MdataK = boxed_matrix_zonotope(second["CK"][0], np.outer(radW, second["sK"][0]))   # :119 then :127
+        self.Mdelta = boxed_matrix_zonotope(np.zeros_like(Cm), np.outer(radW, s))              # :122-123 then :128
         self._drop_native()
         return self.theta, self.Mdata
 
@@ -273,26 +313,68 @@ class TZDDPC(object):
         self.last_status, self.last_iters = st, int(iters[0])
         return float(cost[0]), v[0], xbar[0], self._ze1(np.asarray(xbar0, float).reshape(-1), np.asarray(e0, float).reshape(-1), v[0][0])
 
-    def _ze1(self, xbar0, e0, v0) -> TubeZonotope:
-        """Literal ``Ze[1] = MdataK * <e0,[0]> + (Mdelta * <[xbar0; v0],[0]> + W)`` (``:172-176, :205``).
+    def solve_simplified2(self, xbar0, e0, horizon, Zsigma, build_loss, build_constraints=None, **solver_kwargs):
+        """Reference ``tzddpc/tzddpc.py:381-500``: a one-shot alternative formulation (user-supplied ``Zsigma``, numeric
+        ``theta.deltaA / deltaB``, a ``Ze.sum()`` regulariser) that no example of the reference calls.  It is not on the hot path
+        this package re-implements and has no device kernel; stated loudly instead of approximated."""
+        raise NotImplementedError(
+            "solve_simplified2 (reference tzddpc/tzddpc.py:381-500) is not implemented on the MI355X path: it is unused by the "
+            "reference's examples and relies on un-pinned pyzonotope semantics (CVXZonotope.sum); use build_problem / "
+            "build_problem_simplified + solve")
 
-        Host numpy, for plotting only (``examples/1.double_integrator_sim.py:89-90``); not on the hot path.
-        """
+    def _ze1(self, xbar0, e0, v0) -> TubeZonotope:
+        """Literal ``Ze[1] = MdataK * <e0,[0]> + (Mdelta * <[xbar0; v0],[0]> + W)`` (``:172-176, :205``), columns in the
+        reference's order, evaluated on the device from the stacked generator map (kernel K1g, ``tz_genstack_values``)."""
+        return TubeZonotope(self.ze1_batch(np.asarray(xbar0, float).reshape(1, -1), np.asarray(e0, float).reshape(1, -1),
+                                           np.atleast_1d(np.asarray(v0, float)).reshape(1, -1))[0])
+
+    def _ze1_host(self, xbar0, e0, v0) -> np.ndarray:
+        """The same by literal numpy zonotope algebra (documentation / cross-check of the device export)."""
         n = self.dim_x
         Ze0 = Zonotope(e0, np.zeros((n, 1)))
         XU0 = Zonotope(np.concatenate([xbar0, np.atleast_1d(v0)]), np.zeros((n + self.dim_u, 1)))
-        Z = self.MdataK * Ze0 + (self.Mdelta * XU0 + self.zonotopes.W)
-        return TubeZonotope(Z.Z)
+        return (self.MdataK * Ze0 + (self.Mdelta * XU0 + self.zonotopes.W)).Z
+
+    def ze1_batch(self, xbar0: np.ndarray, e0: np.ndarray, v0: np.ndarray) -> np.ndarray:
+        """``Ze[1].Z.value`` (``n x (1 + Gamma_1)``, ``:377``) of B trajectories: (B, n, 1 + Gamma_1)."""
+        n, m = self.dim_x, self.dim_u
+        if getattr(self, "_gs_ze1", None) is None:
+            from .genstack import build_stack
+            self._gs_ze1 = native.GenStack(self.device, build_stack(self.MdataK, self.Mdelta, self.theta.K, self.zonotopes.W, n, m, 1, None, nseg=2))
+        xbar0 = np.asarray(xbar0, float).reshape(-1, n); B = xbar0.shape[0]
+        zeta = np.concatenate([xbar0, np.asarray(v0, float).reshape(B, m)], axis=1).reshape(B, 1, n + m)
+        return self._gs_ze1.values(1, np.asarray(e0, float).reshape(B, n), zeta)
+
+    def literal_tubes(self, e0: np.ndarray, xbar: np.ndarray, v: np.ndarray):
+        """Interval hulls of the LITERAL tubes ``Ze[k]``, k < N, of the problem last built (``build_problem`` /
+        ``build_problem_simplified``) for B trajectories: the reference's generator stacking (``:172-207`` / ``:283-324``, generator
+        counts growing by gamma_K + 1 per product) evaluated on the device (kernel K1g) -- for ANY generators of MdataK / Mdelta,
+        boxed or dense.  xbar (B, N+1, n), v (B, N, m), e0 (B, n) -> dict(center (B, N, n), rad_x (B, N, n), rad_u (B, N, m)):
+        ``(Ze[k] + xbar[k]).interval`` is ``xbar[k] + center[k] -/+ rad_x[k]``, ``(Ze[k] K + v[k]).interval`` is
+        ``v[k] + K center[k] -/+ rad_u[k]`` (``:191-192``)."""
+        n, m = self.dim_x, self.dim_u
+        N, k0 = self.horizon, self.k0
+        key = (N, k0)
+        if getattr(self, "_gs_full", None) is None or self._gs_full[0] != key:
+            from .genstack import build_stack
+            self._gs_full = (key, native.GenStack(self.device, build_stack(self.MdataK, self.Mdelta, self.theta.K, self.zonotopes.W, n, m, N, k0, nseg=N)))
+        xbar = np.asarray(xbar, float).reshape(-1, N + 1, n); B = xbar.shape[0]
+        zeta = np.concatenate([xbar[:, :N], np.asarray(v, float).reshape(B, N, m)], axis=2)
+        c, rx, ru = self._gs_full[1].intervals(np.asarray(e0, float).reshape(B, n), zeta)
+        return dict(center=c, rad_x=rx, rad_u=ru)
 
     # ---- batched entry points (what the GPU path is for) -------------------------------------------
-    def solve_batch(self, xbar0: np.ndarray, e0: np.ndarray, want_active: bool = False):
-        """B independent ``solve`` calls in one launch sequence.  Returns dict(cost, v, xbar, status, iters[, active])."""
+    def solve_batch(self, xbar0: np.ndarray, e0: np.ndarray, want_active: bool = False, want_ze1: bool = False):
+        """B independent ``solve`` calls in one launch sequence.  Returns dict(cost, v, xbar, status, iters[, active][, ze1]);
+        ``ze1`` (B, n, 1 + Gamma_1) is the 4th return value of the reference's ``solve`` (``:377``) for every trajectory."""
         if self._native is None:
             raise Exception("Problem was not built: call build_problem first")
         v, xbar, cost, status, iters, active = self._native.solve_batch(xbar0, e0, want_active)
         out = dict(cost=cost, v=v, xbar=xbar, status=status, iters=iters)
         if want_active:
             out["active"] = active
+        if want_ze1:
+            out["ze1"] = self.ze1_batch(xbar0, e0, v[:, 0])
         return out
 
     def simulate_batch(self, x0: np.ndarray, noise: np.ndarray, A_true: np.ndarray, B_true: np.ndarray):

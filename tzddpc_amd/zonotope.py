@@ -162,6 +162,14 @@ class MatrixZonotope:
         return f"MatrixZonotope(shape={self.shape}, generators={self.num_generators})"
 
 
+def boxed_matrix_zonotope(center, magnitudes) -> MatrixZonotope:
+    """The matrix zonotope ``reduce(1)`` returns when it boxes everything (Girard order 1, reference ``tzddpc/tzddpc.py:126-128``):
+    one single-entry generator per matrix entry (row-major), magnitude ``magnitudes[r, c]``."""
+    center = np.asarray(center, dtype=float)
+    v = np.asarray(magnitudes, dtype=float).reshape(-1)
+    return MatrixZonotope(center, np.diag(v).reshape((-1,) + center.shape))
+
+
 def concatenate_zonotope(W: Zonotope, num_columns: int) -> MatrixZonotope:
     """n x T matrix zonotope of T independent copies of W (reference ``tzddpc/tzddpc.py:81``)."""
     n, g = W.dimension, W.num_generators
