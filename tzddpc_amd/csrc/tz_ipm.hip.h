@@ -221,13 +221,50 @@ __device__ inline double tz_gemvT_get3(const double* part, int nzp, int c) {
 }
 
 // out[k] = (G in)_r for the rows r = t + 256 k this thread owns; `in` (nz entries) and pl (eg.VL doubles) in LDS.
-template <int MAXR>
+// One lane's walk over its L (value, index) pairs, NL lanes apart.  DEEP: sixteen pairs requested before the first is used instead of
+// four.  Measured on the problems with long walks (DI N=40: 72 pairs per lane in G'v; 5-dim N=20): 10-35 % SLOWER -- the products are
+// bound by the rate at which the lines arrive from L2, not by the round trips -- so it stays off (TZ_ELL_DEEP).
+#ifndef TZ_ELL_DEEP
+#define TZ_ELL_DEEP false
+#endif
+template <bool DEEP>
+__device__ inline double tz_ell_walk(const double* val, const unsigned short* idx, int L, int NL, const double* in) {
+  double a0 = 0.0, a1 = 0.0;
+  int e = 0;
+  if (DEEP) {
+    for (; e + 15 < L; e += 16) {
+      double x[16]; int i[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { x[u] = val[(size_t)(e + u) * NL]; i[u] = idx[(size_t)(e + u) * NL]; }
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) { a0 += x[u] * in[i[u]]; a1 += x[u + 1] * in[i[u + 1]]; }
+    }
+    if (e < L) {                                     // tail: the same sixteen requests, clamped to the last pair and zeroed
+      double x[16]; int i[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const int ee = min(e + u, L - 1); x[u] = val[(size_t)ee * NL]; i[u] = idx[(size_t)ee * NL]; }
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) { a0 += (e + u < L ? x[u] : 0.0) * in[i[u]]; a1 += (e + u + 1 < L ? x[u + 1] : 0.0) * in[i[u + 1]]; }
+    }
+    return a0 + a1;
+  }
+  for (; e + 3 < L; e += 4) {
+    const double x0 = val[(size_t)e * NL], x1 = val[(size_t)(e + 1) * NL], x2 = val[(size_t)(e + 2) * NL], x3 = val[(size_t)(e + 3) * NL];
+    const int i0 = idx[(size_t)e * NL], i1 = idx[(size_t)(e + 1) * NL], i2 = idx[(size_t)(e + 2) * NL], i3 = idx[(size_t)(e + 3) * NL];
+    a0 += x0 * in[i0]; a1 += x1 * in[i1]; a0 += x2 * in[i2]; a1 += x3 * in[i3];
+  }
+  for (; e < L; ++e) a0 += val[(size_t)e * NL] * in[idx[(size_t)e * NL]];
+  return a0 + a1;
+}
+
+template <int MAXR, bool DEEP = false>
 __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double* pl, const int (&rseg)[MAXR], double (&out)[MAXR]) {
   const int t = tz_tid(), L = p.eg.L;
   __syncthreads();                                   // pl may still be read by the owners of the previous product
   for (int v0 = 0; v0 < p.eg.VL; v0 += TZ_THREADS) {
     const double* val = p.eg.val + (size_t)v0 * L + t;
     const unsigned short* idx = p.eg.idx + (size_t)v0 * L + t;
+    if (DEEP) { pl[v0 + t] = tz_ell_walk<true>(val, idx, L, TZ_THREADS, in); continue; }
     double a0 = 0.0, a1 = 0.0;
     int e = 0;
     for (; e + 3 < L; e += 4) {
@@ -252,12 +289,14 @@ __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double*
 
 // Partial sums of G'in by the 192 threads of waves 1-3 (the caller keeps wave 0 out); `in` (mi entries), pl (et.VL doubles) in
 // LDS.  After the next workgroup barrier tz_ell_colsum(pl, cseg) is column c's value for the thread holding cseg = et.seg[c].
+template <bool DEEP = false>
 __device__ inline void tz_ell_gemvT_part(const IpmParams& p, const double* in, double* pl) {
   constexpr int NL = TZ_THREADS - 64;
   const int l = tz_tid() - 64, L = p.et.L;
   for (int v0 = 0; v0 < p.et.VL; v0 += NL) {
     const double* val = p.et.val + (size_t)v0 * L + l;
     const unsigned short* idx = p.et.idx + (size_t)v0 * L + l;
+    if (DEEP) { pl[v0 + l] = tz_ell_walk<true>(val, idx, L, NL, in); continue; }
     double a0 = 0.0, a1 = 0.0;
     int e = 0;
     for (; e + 3 < L; e += 4) {
@@ -862,6 +901,17 @@ __device__ inline bool tz_fwd_trailing(const IpmParams& p, const double* Hq, con
 #define TZ_TT_NST 4
 #endif
 #define TZ_TT_GU(minw) ((minw) >= 2 ? 6 : 8)
+// triangular solves of the tile-triangle class: by 16 x 16 diagonal blocks with explicit block inverses (default) or tile by tile
+#ifndef TZ_TT_BLOCK_SOLVE
+#define TZ_TT_BLOCK_SOLVE 1
+#endif
+#if TZ_TT_BLOCK_SOLVE
+#define TZ_TT_AFTER_CHOL(p, H, dinv) do { tz_tt_block_inverse(p, H, dinv); __syncthreads(); } while (0)
+#define TZ_TT_SOLVE(p, H, dinv, rhs, ybuf, out) tz_chol_solve_blk(p, H, rhs, ybuf, out)
+#else
+#define TZ_TT_AFTER_CHOL(p, H, dinv) do { } while (0)
+#define TZ_TT_SOLVE(p, H, dinv, rhs, ybuf, out) tz_chol_solve_tt(p, H, dinv, rhs, ybuf, out)
+#endif
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip).  hsize: doubles of the factor storage -- nquads * TZ_QSTR in the
 // quad layout (nz <= 64), ntile * TS in the tile-triangle layout; the latter keeps 16 more doubles behind dinv for the factor of
@@ -1044,7 +1094,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     TZ_ROWS(k, r) vin[r] = l_[k];
     __syncthreads();
     if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part);     // P x by wave 0 (stays in `part` for the objective)
-    else tz_ell_gemvT_part(p, vin, pl);                                   // G'lambda by waves 1-3
+    else tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);                                   // G'lambda by waves 1-3
     __syncthreads();
     if (t < nzp) rdv[t] = (t < nz) ? (tz_ell_colsum(pl, cseg) + qv[t]) + part[t] : 0.0;
     __syncthreads();
@@ -1084,7 +1134,7 @@ retry_solve:
     }
     // G x of the starting point: inside a launch gx_ still holds it (it followed x through the iterations of the previous
     // step); it is formed afresh every eighth step so that rounding does not accumulate along a trajectory
-    if (src != 2 || (step & 7) == 0 || retried || shifted) { tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
+    if (src != 2 || (step & 7) == 0 || retried || shifted) { tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
     double viol = 0.0;
     TZ_ROWS(k, r) { const double hv = TZ_H(k, r); viol = fmax(viol, TZ_GX(k, r) - hv); sch = fmax(sch, fabs(hv)); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
@@ -1102,17 +1152,17 @@ retry_solve:
     __syncthreads();
     TZ_ROWS(k, r) vin[r] = TZ_H(k, r);
     __syncthreads();
-    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
+    if (!wave0) tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
     __syncthreads();
     if (t < nzp) r1v[t] = (t < nz) ? tz_ell_colsum(pl, cseg) - qv[t] : 0.0;
     __syncthreads();
-    if constexpr (TT) { okf = tz_cholesky_tt(p, Hq, dinv, dfac, flag); tz_chol_solve_tt(p, Hq, dinv, r1v, tmpz, xv); }
+    if constexpr (TT) { okf = tz_cholesky_tt(p, Hq, dinv, dfac, flag); TZ_TT_AFTER_CHOL(p, Hq, dinv); TZ_TT_SOLVE(p, Hq, dinv, r1v, tmpz, xv); }
     else {
     if (p.chol1) { if (wave0) tz_cholesky_wave(p, Hq, dinv, flag); __syncthreads(); okf = (*flag == 0); }
     else okf = tz_cholesky(p, Hq, dinv, flag);
     if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, xv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
     }
-    tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
+    tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, xv, pl, rseg_, gx_);
     if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; }
   }
   if (!warm) {
@@ -1197,7 +1247,7 @@ retry_solve:
         __builtin_amdgcn_s_setprio(0);
 #endif
       } else {
-        tz_ell_gemvT_part(p, vin, pl);
+        tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
         tz_gemvT_partial<NCG, 1, 3>(p.P, p.nP, nzp, xv, part2);
         // the three waves meet on a counter (wave 0 is busy factoring); wave 1 then assembles the right-hand side and runs the
         // forward substitution one tile column behind the factorisation
@@ -1228,7 +1278,7 @@ retry_solve:
       TZ_STAMP(PH_CHOL);
     } else {
       if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part2);
-      else tz_ell_gemvT_part(p, vin, pl);
+      else tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
       __syncthreads();
       for (int c = t; c < nzp; c += TZ_THREADS) {
         const double pxq = (c < nz) ? part2[c] + qv[c] : 0.0;
@@ -1237,17 +1287,17 @@ retry_solve:
       }
       __syncthreads();
       TZ_STAMP(PH_GEMVT);
-      if constexpr (TT) okc = tz_cholesky_tt(p, Hq, dinv, dfac, flag, (PROF && t == 0) ? acc_ph : nullptr);
+      if constexpr (TT) { okc = tz_cholesky_tt(p, Hq, dinv, dfac, flag, (PROF && t == 0) ? acc_ph : nullptr); TZ_TT_AFTER_CHOL(p, Hq, dinv); }
       else okc = tz_cholesky(p, Hq, dinv, flag, (PROF && t == 0) ? acc_ph : nullptr);
       TZ_STAMP(PH_CHOL);
     }
     if (!okc) { status = 2; break; }
     TZ_FRESH_T();
-    if constexpr (TT) tz_chol_solve_tt(p, Hq, dinv, r1v, tmpz, dxv);
+    if constexpr (TT) TZ_TT_SOLVE(p, Hq, dinv, r1v, tmpz, dxv);
     else if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, have_y ? tmpz : r1v, dxv, have_y); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
-    tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
+    tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, dxv, pl, rseg_, g_);
     TZ_STAMP(PH_GEMV);
 #if TZ_PRIO_ELEM
     __builtin_amdgcn_s_setprio(TZ_PRIO_ELEM);
@@ -1298,16 +1348,16 @@ retry_solve:
 #if TZ_PRIO_ELEM
     __builtin_amdgcn_s_setprio(0);
 #endif
-    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
+    if (!wave0) tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
     __syncthreads();
     for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? -rdv[c] - tz_ell_colsum(pl, cseg) : 0.0;
     __syncthreads();
     TZ_STAMP(PH_GEMVT);
-    if constexpr (TT) tz_chol_solve_tt(p, Hq, dinv, r1v, tmpz, dxv);
+    if constexpr (TT) TZ_TT_SOLVE(p, Hq, dinv, r1v, tmpz, dxv);
     else if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, dxv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
-    tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
+    tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, dxv, pl, rseg_, g_);
     TZ_STAMP(PH_GEMV);
 #if TZ_PRIO_ELEM
     __builtin_amdgcn_s_setprio(TZ_PRIO_ELEM);
@@ -1356,7 +1406,7 @@ retry_solve:
     double hy = 0.0;
     TZ_ROWS(k, r) { const double y = lm_ok ? l_[k] * il : 0.0; vin[r] = y; hy += TZ_H(k, r) * y; }
     __syncthreads();
-    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
+    if (!wave0) tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
     __syncthreads();
     double gmax = fabs(tz_ell_colsum(pl, cseg));
     tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM, 2>(gmax, hy, z2, red, rpar);

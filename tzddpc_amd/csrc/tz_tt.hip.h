@@ -60,16 +60,18 @@ __device__ inline void tz_gram_unit(const IpmParams& p, double* Ht, const double
   unsigned offr[U], offc[U];
 #pragma unroll
   for (int a = 0; a < U; ++a) { offr[a] = (unsigned)min(ib + a, Tz) * 128u; offc[a] = (unsigned)min(jb + a, Tz) * 128u; }
-  const char* gp = (const char*)p.Gp + (unsigned)(4 * k + ij) * 8u;
+  // address = wave-uniform tile base (scalar registers) + one 32-bit lane offset per super-step: no 64-bit vector address arithmetic per load
+  const char* gp = (const char*)p.Gp;
+  const unsigned laneoff = (unsigned)(4 * k + ij) * 8u;
   auto load = [&](int s, TzGuStage<DIAG, U>& st) {
     int kc = 4 * s + blk; kc = (kc < Kc) ? kc : Kc;                       // patch row Kc is all zero, wv[4 Kc + k] = 0
     st.w = wv[4 * kc + k];
-    const char* prow = gp + (unsigned)kc * rowbytes;
+    const unsigned voff = (unsigned)kc * rowbytes + laneoff;
 #pragma unroll
-    for (int a = 0; a < U; ++a) st.vr[a] = tz_ld_pinned((const double*)(prow + offr[a]));
+    for (int a = 0; a < U; ++a) st.vr[a] = tz_ld_pinned((const double*)(gp + offr[a] + (size_t)voff));
     if (!DIAG) {
 #pragma unroll
-      for (int b = 0; b < U; ++b) st.vc[DIAG ? 0 : b] = tz_ld_pinned((const double*)(prow + offc[b]));
+      for (int b = 0; b < U; ++b) st.vc[DIAG ? 0 : b] = tz_ld_pinned((const double*)(gp + offc[b] + (size_t)voff));
     }
   };
   auto mma = [&](const TzGuStage<DIAG, U>& st) {
@@ -208,6 +210,54 @@ __device__ inline void tz_tt_update(double* Ht, int TS, int Tz, int c, int Ifirs
   }
 }
 
+// Phase A of column pp for the waves that do not factor (tz_cholesky_tt), both updates in one pass over the rows below pp:
+//   (i)  tiles (I, pp)     -= L(I, pp-1) L(pp, pp-1)'                    -- finishes column pp
+//   (ii) tiles (I, pp + 1) -= sum_{k2 < pp} L(I, k2) L(pp+1, k2)'        -- column pp + 1 (incl. its diagonal tile) up to date with the columns < pp
+// for I = pp + 1 + 4 g + blk, row groups g = gfirst, gfirst + gstep, ...  The A operands L(I, k2) are shared by the two columns;
+// the C tiles and the first operands of both are requested together (one LDS round trip up front instead of two calls' worth),
+// all addresses advance by constants (no integer multiplies in the loop).
+__device__ inline void tz_tt_phase_a(double* Ht, int TS, int Tz, int pp, int gfirst, int gstep) {
+  const int lane = tz_tid() & 63;
+  const int k = lane >> 4, blk = (lane >> 2) & 3, ij = lane & 3;
+  const int lo = 4 * ij + k;                                               // element [ij][k] of an operand tile
+  const bool two = pp + 1 < Tz;                                            // column pp + 1 exists
+  const double* pb1 = Ht + (tz_tri(pp) + pp - 1) * TS + lo;                // L(4pp + j, 4(pp-1) + k')
+  const double* pb2 = Ht + tz_tri(two ? pp + 1 : pp) * TS + lo;            // L(4(pp+1) + j, 4 k2 + k'), k2 = 0 ...
+  for (int g = gfirst; pp + 1 + 4 * g < Tz; g += gstep) {                  // (two groups at a time was slower: most columns leave one group per wave)
+    const int I = pp + 1 + 4 * g + blk;
+    const bool v = I < Tz;
+    const int tI = tz_tri(v ? I : pp) * TS;
+    const double* pa = Ht + tI + lo;                                       // L(4I + i, 4 k2 + k'), k2 = 0 ...
+    double* pc1 = Ht + tI + pp * TS + 4 * k + ij;                          // H(4I + i', 4pp + j')
+    double* pc2 = pc1 + TS;                                                // H(4I + i', 4(pp+1) + j')   (I >= pp + 1: inside the triangle)
+    double c1 = tz_ld_pinned(pc1), c2 = two ? tz_ld_pinned(pc2) : 0.0, c3 = 0.0;
+    const double alast = tz_ld_pinned(pa + (pp - 1) * TS), b1 = tz_ld_pinned(pb1);
+    if (two) {
+      const int nk = pp, klast = nk - 1;
+      auto ld = [&](int k2, double& a, double& b) { const int o = min(k2, klast) * TS; a = tz_ld_pinned(pa + o); b = tz_ld_pinned(pb2 + o); };
+      double a0, b0, a1, b1n, a2, b2, a3, b3;
+      ld(0, a0, b0); ld(1, a1, b1n); ld(2, a2, b2); ld(3, a3, b3);
+      c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(alast, -b1, c1, 0, 0, 0);
+      int k2 = 0;
+      for (; k2 + 3 < nk; k2 += 4) {                                       // operands four columns ahead
+        const double x0 = a0, y0 = -b0, x1 = a1, y1 = -b1n, x2 = a2, y2 = -b2, x3 = a3, y3 = -b3;
+        ld(k2 + 4, a0, b0); ld(k2 + 5, a1, b1n); ld(k2 + 6, a2, b2); ld(k2 + 7, a3, b3);
+        c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(x0, y0, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_4x4x4f64(x1, y1, c3, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(x2, y2, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_4x4x4f64(x3, y3, c3, 0, 0, 0);
+      }
+      if (k2 < nk) c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, -b0, c2, 0, 0, 0);
+      if (k2 + 1 < nk) c3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, -b1n, c3, 0, 0, 0);
+      if (k2 + 2 < nk) c2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2, -b2, c2, 0, 0, 0);
+      if (v) { *pc1 = c1; *pc2 = c2 + c3; }
+    } else {
+      c1 = __builtin_amdgcn_mfma_f64_4x4x4f64(alast, -b1, c1, 0, 0, 0);
+      if (v) *pc1 = c1;
+    }
+  }
+}
+
 // dfac (LDS, 10 doubles): l10 l20 l21 l30 l31 l32 i00 i11 i22 i33 of the diagonal tile being eliminated
 __device__ inline bool tz_cholesky_tt(const IpmParams& p, double* Ht, double* dinv, double* dfac, int* flag, unsigned long long* pacc = nullptr) {
   const int Tz = p.Tz, TS = p.TS;
@@ -264,8 +314,16 @@ __device__ inline bool tz_cholesky_tt(const IpmParams& p, double* Ht, double* di
       __builtin_amdgcn_s_setprio(0);
 #endif
     } else if (pp > 0) {
-      tz_tt_update(Ht, TS, Tz, pp, pp + 1, pp - 1, pp, wave - 1, 3);           // (i)  column pp, rows > pp, minus column pp - 1
-      if (pp + 1 < Tz) tz_tt_update(Ht, TS, Tz, pp + 1, pp + 1, 0, pp, wave - 1, 3);   // (ii) column pp + 1 (incl. its diagonal tile), columns < pp
+#if TZ_PROFILE
+      unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
+      tz_tt_phase_a(Ht, TS, Tz, pp, wave - 1, 3);                               // (i) + (ii), see there
+#if TZ_PROFILE
+      unsigned long long tw1 = __builtin_amdgcn_s_memtime();
+#endif
+#if TZ_PROFILE
+      if (p.prof && blockIdx.x == 0 && threadIdx.x == 64) { unsigned long long tw2 = __builtin_amdgcn_s_memtime(); atomicAdd(p.prof + 32, tw1 - tw0); atomicAdd(p.prof + 33, tw2 - tw1); }
+#endif
     }
     if (pacc) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); pacc[PH_CH_DIAG] += t1 - tc0; tc0 = t1; }
     __syncthreads();
@@ -290,6 +348,138 @@ __device__ inline bool tz_cholesky_tt(const IpmParams& p, double* Ht, double* di
     if (pacc) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); pacc[PH_CH_BAR] += t1 - tc0; tc0 = t1; }
   }
   return *flag == 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Block-diagonal inverses for the triangular solves.  Substitution tile by tile is a chain of Tz dependent steps of ~500 cycles
+// each (cross-lane broadcast, 4x4 inverse, update); with the inverse W_Q = inv(L_QQ) of every 16 x 16 diagonal block the chain
+// has Tz / 4 steps: y_Q = W_Q (r_Q - sum_{P<Q} L_QP y_P).  W_Q is built from the 4x4 tile inverses M_I the factorisation
+// leaves in dinv:   W(I, I) = M_I,   W(I, J) = -M_I sum_{J <= K < I} L(I, K) W(K, J)   (tile rows I, J of the block),
+// and overwrites the tiles of L_QQ (diagonal tiles included: the factorisation never stores them, the solves never read L there).
+// One lane per column of W (16 lanes per block, four blocks per wave pass); all reads of a block precede its writes (lockstep).
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ inline void tz_tt_block_inverse(const IpmParams& p, double* Ht, const double* dinv) {
+  const int Tz = p.Tz, TS = p.TS, nb = (Tz + 3) >> 2;
+  const int t = tz_tid(), wave = t >> 6, lane = t & 63;
+  for (int Q0 = 4 * wave; Q0 < nb; Q0 += 4 * TZ_NWAVES) {
+    const int Q = Q0 + (lane >> 4), c = lane & 15, cj = c >> 2, ce = c & 3;     // column c of block Q: tile column cj, element ce
+    const bool vq = Q < nb;
+    const int R0 = 4 * (vq ? Q : 0);
+    // tile row by tile row; the finished part of the column lives in LDS (tiles (K, cj), K < I: already W) and is read back, so
+    // that only one tile row of operands is in registers at a time (the kernel is at its register budget here).  Lanes of a wave
+    // run in lockstep: every read of tile row I precedes the writes of tile row I.
+    for (int I = 0; I < 4; ++I) {
+      const bool vi = vq && (R0 + I < Tz);
+      const int ti = tz_tri(vi ? R0 + I : 0);
+      double a0 = (I == cj && ce == 0) ? 1.0 : 0.0, a1 = (I == cj && ce == 1) ? 1.0 : 0.0;
+      double a2 = (I == cj && ce == 2) ? 1.0 : 0.0, a3 = (I == cj && ce == 3) ? 1.0 : 0.0;      // e_c restricted to tile row I - sum_K L(I, K) w_K
+      for (int K = cj; K < I; ++K) {                                            // w_K = 0 above the column's first tile row
+        const double* wk = Ht + (tz_tri(vi ? R0 + K : 0) + R0 + cj) * TS + ce;     // W(4K + e, c), e = 0..3: stride 4
+        const double w0 = wk[0], w1 = wk[4], w2 = wk[8], w3 = wk[12];
+        const double* l = Ht + (ti + R0 + K) * TS;
+        a0 -= (l[0] * w0 + l[1] * w1) + (l[2] * w2 + l[3] * w3);
+        a1 -= (l[4] * w0 + l[5] * w1) + (l[6] * w2 + l[7] * w3);
+        a2 -= (l[8] * w0 + l[9] * w1) + (l[10] * w2 + l[11] * w3);
+        a3 -= (l[12] * w0 + l[13] * w1) + (l[14] * w2 + l[15] * w3);
+      }
+      const double* m = dinv + (vi ? R0 + I : 0) * 16;                           // M_I, lower triangular
+      const double v0 = m[0] * a0;
+      const double v1 = m[4] * a0 + m[5] * a1;
+      const double v2 = (m[8] * a0 + m[9] * a1) + m[10] * a2;
+      const double v3 = (m[12] * a0 + m[13] * a1) + (m[14] * a2 + m[15] * a3);
+      tz_wave_sync();                                                            // all lanes have read tile row I
+      if (vi && I >= cj) {
+        double* o = Ht + (ti + R0 + cj) * TS + ce;
+        o[0] = v0; o[4] = v1; o[8] = v2; o[12] = v3;
+      }
+      tz_wave_sync();                                                            // W of tile row I visible to the reads of the next rows
+    }
+  }
+}
+
+// (L L') out = rhs with the block inverses in place (tz_tt_block_inverse): thread t owns row t, a block of 16 rows is one DPP row
+// of 16 lanes.  Block step Q, forward: the owners form y_Q = W_Q r_Q -- every lane needs the 16 residuals of its row of lanes:
+// fifteen DPP row rotations against the pre-rotated row of W (wrot[k] = W[r][(r - k) mod 16], fetched ahead) -- and publish it in
+// LDS; after one barrier every later row subtracts L(t, block Q) y_Q (16 FMAs, own row of L, y broadcast).  Backward: mirror image
+// with the columns of W and of L.  ybuf: nzp doubles of LDS.
+template <int K> struct TzRor { static __device__ inline double get(double v) { return tz_row_ror<K>(v); } };
+template <> struct TzRor<0> { static __device__ inline double get(double v) { return v; } };
+
+template <bool FWD>
+__device__ inline double tz_tt_block_apply(const double (&wrot)[16], double rv) {
+  // FWD: sum_k wrot[k] * rv[(lane - k) mod 16];  !FWD: sum_k wrot[k] * rv[(lane + k) mod 16]   (row_ror:N reads lane - N)
+  double s0 = wrot[0] * rv, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#define TZ_BA(kk, acc) acc += wrot[kk] * (FWD ? TzRor<kk>::get(rv) : TzRor<16 - kk>::get(rv))
+  TZ_BA(1, s1); TZ_BA(2, s2); TZ_BA(3, s3); TZ_BA(4, s0); TZ_BA(5, s1); TZ_BA(6, s2); TZ_BA(7, s3);
+  TZ_BA(8, s0); TZ_BA(9, s1); TZ_BA(10, s2); TZ_BA(11, s3); TZ_BA(12, s0); TZ_BA(13, s1); TZ_BA(14, s2); TZ_BA(15, s3);
+#undef TZ_BA
+  return (s0 + s1) + (s2 + s3);
+}
+
+__device__ inline void tz_chol_solve_blk(const IpmParams& p, const double* Ht, const double* rhs, double* ybuf, double* out) {
+  const int Tz = p.Tz, nzp = p.nzp, TS = p.TS, nb = (Tz + 3) >> 2;
+  const int t = tz_tid(), jq = t & 3, tq = t >> 2, blkQ = t >> 4, r = t & 15;   // row t = 16 blkQ + r
+  const bool live = t < nzp;
+  double rv = live ? rhs[t] : 0.0;
+  const double* rowp = Ht + tz_tri(live ? tq : 0) * TS + 4 * jq;                 // L(t, 4J + e) = rowp[J TS + e]
+  // rows of L / columns of L' against one block of 16 unknowns (yy): the update every row outside the block takes
+  auto row_dot = [&](int Q, const double* yy) {
+    const double* lr = rowp + 4 * Q * TS;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+      a0 += lr[J * TS] * yy[4 * J] + lr[J * TS + 2] * yy[4 * J + 2];
+      a1 += lr[J * TS + 1] * yy[4 * J + 1] + lr[J * TS + 3] * yy[4 * J + 3];
+    }
+    return a0 + a1;
+  };
+  auto col_dot = [&](int Q, const double* xx) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+      const int I = 4 * Q + J;
+      if (I < Tz) {
+        const double* lc = Ht + (tz_tri(I) + tq) * TS + jq;
+        a0 += lc[0] * xx[4 * J] + lc[8] * xx[4 * J + 2];
+        a1 += lc[4] * xx[4 * J + 1] + lc[12] * xx[4 * J + 3];
+      }
+    }
+    return a0 + a1;
+  };
+  // ---- forward (one workgroup barrier per block: running the four blocks of a wave wave-synchronously, with a barrier per 64
+  // rows only, measured 20 % slower -- the updates of the other waves' rows then wait for all four) -----------------------------
+  {
+    double wrot[16];                                                              // W[r][(r - k) mod 16]: zero above the diagonal (k > r)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int c = (r - k) & 15; wrot[k] = (live && k <= r) ? rowp[(4 * blkQ + (c >> 2)) * TS + (c & 3)] : 0.0; }
+    for (int Q = 0; Q < nb; ++Q) {
+      const double y = tz_tt_block_apply<true>(wrot, rv);
+      if (blkQ == Q && live) { rv = y; ybuf[t] = y; }
+      if (Q + 1 < nb) {
+        __syncthreads();
+        if (blkQ > Q && live) rv -= row_dot(Q, ybuf + 16 * Q);
+      }
+    }
+  }
+  __syncthreads();                                                               // ybuf is reused by the backward sweep
+  // ---- backward -------------------------------------------------------------------------------------------------------
+  {
+    double wrot[16];                                                              // W[(r + k) mod 16][r]: zero when r + k wraps (rows above) or beyond the matrix
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int rr = r + k, I = 4 * blkQ + (rr >> 2);
+      wrot[k] = (live && rr < 16 && I < Tz) ? Ht[(tz_tri(I) + tq) * TS + 4 * (rr & 3) + jq] : 0.0;
+    }
+    for (int Q = nb - 1; Q >= 0; --Q) {
+      const double x = tz_tt_block_apply<false>(wrot, rv);
+      if (blkQ == Q && live) { rv = x; ybuf[t] = x; }
+      if (Q > 0) {
+        __syncthreads();
+        if (blkQ < Q) rv -= col_dot(Q, ybuf + 16 * Q);                            // rows above take this block's x: column t of L(block Q, :)
+      }
+    }
+  }
+  if (live) out[t] = rv;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

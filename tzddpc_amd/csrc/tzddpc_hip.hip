@@ -882,7 +882,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (const char* e = getenv("TZ_AFF_THR")) p->aff_thr = atof(e);
   if (const char* e = getenv("TZ_AFF_MU")) p->aff_mu = atof(e);
   if (const char* e = getenv("TZ_STEP_FRAC")) { double v = atof(e); if (v > 0 && v < 1) p->step_frac = v; }
-  if (p->prof) TZ_HIP(p->prof_buf.alloc(PH_COUNT));
+  if (p->prof) { TZ_HIP(p->prof_buf.alloc(PH_COUNT + 16)); TZ_HIP(hipMemset(p->prof_buf.p, 0, (PH_COUNT + 16) * sizeof(unsigned long long))); }
   TZ_HIP(p->work_buf.alloc(2));
   TZ_HIP(hipMemset(p->work_buf.p, 0, 2 * sizeof(unsigned long long)));
   TZ_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -1133,11 +1133,12 @@ int tz_debug_fetch(tz_problem* p, int32_t b, int what, double* out, int32_t capa
     case 5: src = p->lam.p + (size_t)b * p->mi; len = p->mi; break;
     case 6: {   // diagnostic build: per-phase cycle sums of workgroup 0 (as doubles)
       if (!p->prof) TZ_FAIL(TZ_ERR_INVALID, "profiling build not enabled (TZ_PROF=1 at problem creation)");
-      unsigned long long h[PH_COUNT];
+      unsigned long long h[PH_COUNT + 16];
       TZ_HIP(hipMemcpy(h, p->prof_buf.p, sizeof(h), hipMemcpyDeviceToHost));
-      if (capacity < PH_COUNT) TZ_FAIL(TZ_ERR_INVALID, "capacity too small");
-      for (int i = 0; i < PH_COUNT; ++i) out[i] = (double)h[i];
-      return PH_COUNT;
+      if (capacity < PH_COUNT + 16) TZ_FAIL(TZ_ERR_INVALID, "capacity too small");
+      for (int i = 0; i < PH_COUNT + 16; ++i) out[i] = (double)h[i];
+      TZ_HIP(hipMemset(p->prof_buf.p + 32, 0, 6 * sizeof(unsigned long long)));      // slots 32..37: sums of other waves (atomics), restart
+      return PH_COUNT + 16;
     }
     case 7: {   // interior-point iterations of every trajectory of the last launch (b ignored)
       if (capacity < p->lastB) TZ_FAIL(TZ_ERR_INVALID, "capacity %d < %d", capacity, p->lastB);

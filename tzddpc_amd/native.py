@@ -324,7 +324,7 @@ class Problem:
         return out[:n].astype(np.int64)
 
     def debug_fetch(self, b: int, what: int) -> np.ndarray:
-        cap = max(self.nz, self.mi, self.ntheta, 32)
+        cap = max(self.nz, self.mi, self.ntheta, 64)
         out = np.empty(cap)
         n = check(lib().tz_debug_fetch(self._h, int(b), int(what), out.ctypes.data_as(C.c_void_p), cap), "tz_debug_fetch")
         return out[:n].copy()
