@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TZ_ABI_VERSION 2
+#define TZ_ABI_VERSION 3
 
 typedef enum tz_status {
   TZ_OK = 0,
@@ -140,6 +140,27 @@ int tz_device_count(int* count);
 int tz_identify_batch(int device, int32_t B, int32_t T, int32_t n, int32_t m, const double* u, const double* x,
                       const double* w_center, const double* K, int32_t k_shared,
                       double* C, double* s, double* sK, double* CK, int32_t* status, int mem);
+
+/*
+ * Gain synthesis without MOSEK (reference tzddpc/utils.py).  Both calls evaluate closed-loop matrices
+ *     M(beta) = M0 + sum_i beta_i H_i        (n x n, n <= 8; H : ngen x n x n row-major; host pointers; blocking)
+ * for S coefficient vectors at once, one GPU lane per vector.
+ *
+ * tz_specrad_batch -- the sampling test of is_gain_robust (reference tzddpc/utils.py:105-129): with M0 = A0 + B0 K,
+ *   H_i = G_i[:, :n] + G_i[:, n:] K and beta = S samples of Mdata.sample()'s coefficients, rho[s] = spectral_radius(A + B K)
+ *   (:8-11; in-LDS Hessenberg reduction + Francis double-shift QR per lane), status[s] = 0 or TZ_NUMERICAL (QR did not converge).
+ *
+ * tz_adversary_batch -- the adversarial model search of compute_A_B (reference tzddpc/utils.py:13-41): maximise ||A + B K||_F
+ *   over independent beta_A, beta_B in [-1, 1]^gamma, H = [G_i[:, :n]]_i followed by [G_i[:, n:] K]_i (ngen = 2 gamma).  From
+ *   every starting point beta0[s] the convex-concave procedure the reference delegates to DCCP (:37) is iterated to its fixed
+ *   point: one step sets all beta_i = sign <M(beta), H_i> (the vertex of the box that maximises the linearised objective; a zero
+ *   inner product keeps beta_i).  beta[s] (out) = the fixed point, fro[s] = ||M(beta[s])||_F, steps[s] = CCP steps taken
+ *   (<= max_iter).  The caller keeps the best start (the reference's ccp_times = num_init).
+ */
+int tz_specrad_batch(int device, int32_t S, int32_t n, int32_t ngen, const double* M0, const double* H, const double* beta,
+                     double* rho, int32_t* status);
+int tz_adversary_batch(int device, int32_t S, int32_t n, int32_t ngen, const double* M0, const double* H, const double* beta0,
+                       int32_t max_iter, double* beta, double* fro, int32_t* steps);
 
 /*
  * K1g -- literal stacked-generator tubes (the general path: any generators of MdataK / Mdelta, boxed or dense).

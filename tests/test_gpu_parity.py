@@ -575,3 +575,95 @@ def test_literal_tubes_dense_generators_and_collapsed_where_exact(built):
             np.testing.assert_allclose(out["center"][b, k], cc, rtol=0, atol=1e-12)
             np.testing.assert_allclose(out["rad_x"][b, k], rx, rtol=0, atol=1e-11 * (1 + rx.max()))
             np.testing.assert_allclose(out["rad_u"][b, k], ru, rtol=0, atol=1e-11 * (1 + ru.max()))
+
+
+# ---- gain synthesis on the device -------------------------------------------------------------------
+def _unreduced_mdata(sysname, seed=25):
+    """Un-reduced Mdata of a benchmark data set through the ORACLE's identification (reference tzddpc/tzddpc.py:81-83)."""
+    from oracle import harness as H
+    from oracle.zonolite import compute_LTI_matrix_zonotope, concatenate_zonotope
+    s = H.system(sysname)
+    rng = np.random.default_rng(seed)
+    u, x = H.generate_trajectories(s["A"], s["B"], s["X0"], s["U"], s["W"], 1, s["T"], rng)
+    Mo = compute_LTI_matrix_zonotope(x[:-1], x[1:], u[:-1], concatenate_zonotope(s["W"], x.shape[0] - 1))
+    from tzddpc_amd.zonotope import MatrixZonotope
+    return s, Mo, MatrixZonotope(np.asarray(Mo.center), np.asarray(Mo.generators))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_spectral_radius_kernel_matches_lapack(built, n):
+    """tz_specrad_batch (in-LDS Hessenberg + Francis QR per lane) against numpy.linalg.eigvals on random, triangular, zero, identity
+    and cyclic-permutation matrices (the last needs the exceptional shifts), <= 1e-10 relative."""
+    from tzddpc_amd import native
+    rng = np.random.default_rng(100 + n)
+    S = 1500
+    M = rng.standard_normal((S, n, n))
+    M[:100] = np.triu(M[:100]); M[100:150] = 0.0; M[150:200] = np.eye(n)
+    if n >= 2:
+        M[200:260] = 0.0; M[200:260, np.arange(n - 1) + 1, np.arange(n - 1)] = 1.0; M[200:260, 0, n - 1] = 1.0
+    H = np.eye(n * n).reshape(n * n, n, n)                       # beta = the entries: arbitrary matrices through the zonotope form
+    rho, status = native.specrad_batch(0, np.zeros((n, n)), H, M.reshape(S, n * n))
+    ref = np.abs(np.linalg.eigvals(M)).max(axis=1)
+    assert (status == 0).all()
+    assert (np.abs(rho - ref) / (1.0 + ref)).max() <= 1e-10
+
+
+@pytest.mark.parametrize("sysname", ["di_cc", "di_sim", "pulley", "dim5_w001"])
+def test_gain_robustness_and_adversary_match_oracle(built, sysname):
+    """is_gain_robust (reference tzddpc/utils.py:105-129) and compute_A_B (:13-41) on the un-reduced Mdata of the benchmark data
+    sets: the 1146 sampled spectral radii against the oracle (<= 1e-10), the CCP fixed points of the adversarial search identical
+    to the oracle's (same signs, same step counts, norm <= 1e-12 relative), and the returned (An, Bn)."""
+    from oracle import gain as OG
+    from tzddpc_amd import gain as PG, native
+    s, Mo, Mp = _unreduced_mdata(sysname)
+    n = s["A"].shape[0]
+    K = OG.compute_control_gain(Mo.center[:, :n], Mo.center[:, n:])[0]
+    np.testing.assert_allclose(PG.compute_control_gain(Mp.center[:, :n], Mp.center[:, n:]), K, atol=1e-12)
+    g = Mp.num_generators
+    num = OG.num_robust_samples(1e-2, 1e-5)
+    assert num == 1146 == PG.num_robust_samples(1e-2, 1e-5)
+    rng = np.random.default_rng(3)
+    beta = rng.uniform(-1.0, 1.0, size=(num, g))
+    ref = OG.sampled_radii(Mo, K, beta)
+    M0 = Mp.center[:, :n] + Mp.center[:, n:] @ K
+    H = Mp.generators[:, :, :n] + Mp.generators[:, :, n:] @ K
+    rho, status = native.specrad_batch(0, M0, H, beta)
+    assert (status == 0).all()
+    assert np.abs(rho - ref).max() <= 1e-10
+    assert PG.is_gain_robust(Mp, K, 1e-2, 1e-5, device=0, beta=beta) == OG.is_gain_robust(Mo, K, 1e-2, 1e-5, beta)
+    assert PG.is_gain_robust(Mp, 0.0 * K, 1e-2, 1e-5, device=0, beta=beta) == OG.is_gain_robust(Mo, 0.0 * K, 1e-2, 1e-5, beta)
+    # adversarial search: 200 starting points
+    beta0 = rng.uniform(-1.0, 1.0, size=(200, 2 * g))
+    M0a, Ha = OG.adversary_generators(Mo, K)
+    bdev, fro, steps = native.adversary_batch(0, M0a, Ha, beta0, 100)
+    for i in range(0, 200, 7):
+        b, f, st = OG.ccp_ascent(M0a, Ha, beta0[i])
+        assert np.array_equal(b, bdev[i]) and st == steps[i]
+        assert abs(f - fro[i]) <= 1e-12 * (1 + f)
+    assert (np.abs(bdev) == 1.0).all() or (np.abs(bdev) <= 1.0).all()
+    An, Bn = PG.compute_A_B(Mp, K, device=0, beta0=beta0)
+    Ao, Bo, fo = OG.compute_A_B(Mo, K, beta0)
+    np.testing.assert_allclose(An, Ao, atol=1e-12); np.testing.assert_allclose(Bn, Bo, atol=1e-12)
+    assert abs(np.linalg.norm(An + Bn @ K) - fro.max()) <= 1e-10
+
+
+def test_compute_theta_synthesis_matches_oracle(built):
+    """The reference's alternation (tzddpc/utils.py:60-103) with the device kernels against the oracle's restatement on the
+    double-integrator data: same gain, same adversarial deltas (same random stream), gain accepted by the robustness test; and
+    through the controller (build_zonotopes_theta(synthesize=True))."""
+    from oracle import gain as OG
+    from tzddpc_amd import TZDDPC, gain as PG
+    from tzddpc_amd.harness import generate_trajectories, system
+    s, Mo, Mp = _unreduced_mdata("di_sim")
+    n = 2
+    A0, B0 = Mp.center[:, :n], Mp.center[:, n:]
+    th = PG.compute_theta(Mp, A0, B0, synthesize=True, device=0, rng=np.random.default_rng(11))
+    Ko, dAo, dBo, log = OG.compute_theta(Mo, A0, B0, np.random.default_rng(11))
+    np.testing.assert_allclose(th.K, Ko, atol=1e-12)
+    np.testing.assert_allclose(th.deltaA, dAo, atol=1e-12); np.testing.assert_allclose(th.deltaB, dBo, atol=1e-12)
+    assert np.abs(th.deltaA).max() > 0 and log[-1][0] < 1
+    A, B, zon, T = system("di_sim")
+    ctl = TZDDPC(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, np.random.default_rng(25)), device=0)
+    theta, _ = ctl.build_zonotopes_theta(zon, synthesize=True, rng=np.random.default_rng(11))
+    assert PG.spectral_radius(ctl.Mdata.center[:, :n] + ctl.Mdata.center[:, n:] @ theta.K) < 1
+    assert theta.deltaA.shape == (2, 2) and theta.deltaB.shape == (2, 1) and np.abs(theta.deltaB).max() > 0

@@ -6,7 +6,7 @@ Drop-in surface of the reference package (``tzddpc/__init__.py:1-15``): ``TZDDPC
 (use ``from tzddpc_amd import cplite as cp`` where the examples ``import cvxpy as cp``).
 """
 from . import cplite
-from .gain import compute_theta, is_gain_robust, lqr_gain, spectral_radius
+from .gain import compute_A_B, compute_control_gain, compute_theta, is_gain_robust, lqr_gain, spectral_radius
 from .objects import (Data, DataDrivenDataset, OptimizationProblem, OptimizationProblemVariables, SystemZonotopes, Theta)
 from .tzddpc import TZDDPC, TubeZonotope
 from .zonotope import Interval, MatrixZonotope, Zonotope, compute_LTI_matrix_zonotope, concatenate_zonotope
@@ -14,4 +14,4 @@ from .zonotope import Interval, MatrixZonotope, Zonotope, compute_LTI_matrix_zon
 __version__ = "0.1.0"
 __all__ = ["TZDDPC", "TubeZonotope", "Data", "DataDrivenDataset", "SystemZonotopes", "Theta", "OptimizationProblem",
            "OptimizationProblemVariables", "Zonotope", "MatrixZonotope", "Interval", "concatenate_zonotope",
-           "compute_LTI_matrix_zonotope", "compute_theta", "is_gain_robust", "lqr_gain", "spectral_radius", "cplite"]
+           "compute_LTI_matrix_zonotope", "compute_theta", "compute_A_B", "compute_control_gain", "is_gain_robust", "lqr_gain", "spectral_radius", "cplite"]

@@ -190,6 +190,7 @@ struct FuseParams {
 #include "tz_ipm.hip.h"
 #include "tz_identify.hip.h"
 #include "tz_genstack.hip.h"
+#include "tz_gain.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // Finish: one wave per trajectory.

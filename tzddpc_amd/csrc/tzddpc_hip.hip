@@ -401,6 +401,45 @@ int tz_identify_batch(int device, int32_t B, int32_t T, int32_t n, int32_t m, co
   return TZ_OK;
 }
 
+// ---- gain synthesis (tz_gain.hip.h): spectral radii of sampled closed loops, CCP ascent of ||A + B K||_F ------------------------
+static int gain_batch(bool adversary, int device, int32_t S, int32_t n, int32_t ngen, const double* M0, const double* H,
+                      const double* beta, int32_t max_iter, double* beta_out, double* val, int32_t* aux) {
+  if (!M0 || !beta || !val || !aux || (ngen > 0 && !H) || (adversary && !beta_out)) TZ_FAIL(TZ_ERR_INVALID, "null argument");
+  if (S <= 0 || ngen < 0) TZ_FAIL(TZ_ERR_INVALID, "S must be positive, ngen non-negative");
+  if (n < 1 || n > TZ_GN_NMAX) TZ_FAIL(TZ_ERR_UNSUPPORTED, "dim_x must be 1..%d", TZ_GN_NMAX);
+  if (adversary && max_iter < 1) TZ_FAIL(TZ_ERR_INVALID, "max_iter must be positive");
+  int ndev = 0;
+  TZ_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) TZ_FAIL(TZ_ERR_HIP, "no HIP device visible: the TZDDPC hot path has no CPU fallback");
+  if (device < 0 || device >= ndev) TZ_FAIL(TZ_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+  TZ_HIP(hipSetDevice(device));
+  const size_t s = (size_t)S, g = (size_t)ngen, n2 = (size_t)n * n;
+  DevBuf<double> dM0, dH, dbeta, dbout, dval; DevBuf<int> daux;
+  TZ_HIP(dM0.upload(M0, n2));
+  if (g) { TZ_HIP(dH.upload(H, g * n2)); TZ_HIP(dbeta.upload(beta, s * g)); } else { TZ_HIP(dH.alloc(1)); TZ_HIP(dbeta.alloc(1)); }
+  TZ_HIP(dval.alloc(s)); TZ_HIP(daux.alloc(s));
+  if (adversary) TZ_HIP(dbout.alloc(std::max<size_t>(s * g, 1)));
+  GainParams q{S, n, ngen, max_iter, dM0.p, dH.p, dbeta.p, adversary ? dbout.p : nullptr, dval.p, daux.p};
+  const dim3 grid((S + 63) / 64), block(64);
+  if (adversary) hipLaunchKernelGGL(tz_adversary_kernel, grid, block, 0, 0, q);
+  else hipLaunchKernelGGL(tz_specrad_kernel, grid, block, 0, 0, q);
+  TZ_HIP(hipGetLastError());
+  TZ_HIP(hipMemcpy(val, dval.p, s * sizeof(double), hipMemcpyDeviceToHost));
+  TZ_HIP(hipMemcpy(aux, daux.p, s * sizeof(int), hipMemcpyDeviceToHost));
+  if (adversary && g) TZ_HIP(hipMemcpy(beta_out, dbout.p, s * g * sizeof(double), hipMemcpyDeviceToHost));
+  return TZ_OK;
+}
+
+int tz_specrad_batch(int device, int32_t S, int32_t n, int32_t ngen, const double* M0, const double* H, const double* beta,
+                     double* rho, int32_t* status) {
+  return gain_batch(false, device, S, n, ngen, M0, H, beta, 0, nullptr, rho, status);
+}
+
+int tz_adversary_batch(int device, int32_t S, int32_t n, int32_t ngen, const double* M0, const double* H, const double* beta0,
+                       int32_t max_iter, double* beta, double* fro, int32_t* steps) {
+  return gain_batch(true, device, S, n, ngen, M0, H, beta0, max_iter, beta, fro, steps);
+}
+
 struct tz_genstack {
   int device = 0, n = 0, m = 0, N = 0, nseg = 0, rec = 0, nchunk = 0;
   int64_t G = 0;

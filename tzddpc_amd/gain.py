@@ -1,14 +1,17 @@
-"""Feedback-gain helpers (offline, one-shot; NOT on the per-step path).
+"""Gain synthesis (offline, one-shot; NOT on the per-step path) -- SURVEY.md section 8 row f-3.
 
-The reference synthesises K by alternating an LMI feasibility problem with a DCCP/MOSEK
-adversarial search (reference ``tzddpc/utils.py:43-103``); both need cvxpy, dccp and a commercial
-MOSEK licence and return a solver-dependent feasible point.  That loop is out of scope
-(SURVEY.md section 2 row 7): K is an input of the hot path.  Provided here:
+The reference synthesises K by alternating an LMI feasibility problem (cvxpy SDP, reference ``tzddpc/utils.py:43-58``) with an
+adversarial model search handed to DCCP + MOSEK (``:13-41``) and accepts it after a sampling test (``:105-129``).  Here:
 
-  * ``lqr_gain``          default gain when the caller supplies none (Riccati on the identified model)
-  * ``spectral_radius``   reference ``utils.py:8-11``
-  * ``is_gain_robust``    reference ``utils.py:105-129`` (same sample-size formula, numpy only)
-  * ``compute_theta``     passthrough / LQR + robustness check with the reference's signature
+  * ``compute_control_gain``  a point of the same LMI's feasible set from the discrete Riccati equation (host, n <= 8), with
+                              ``lmi_point`` returning the (X, Z) that certify it
+  * ``compute_A_B``           the same maximisation, the convex-concave steps DCCP would take iterated on the GPU from all starting
+                              points at once (``tz_adversary_batch``)
+  * ``is_gain_robust``        the same sampling test with the spectral radii of all samples computed on the GPU
+                              (``tz_specrad_batch``; ``device=None`` keeps the small numpy evaluation for GPU-less build hosts)
+  * ``compute_theta``         the reference's alternation (``:60-103``) when ``synthesize=True``; otherwise the gain is a fixture
+                              (``K=``) or the LQR gain of the identified model, as in the earlier rounds
+  * ``lqr_gain``, ``spectral_radius`` (``:8-11``)
 """
 from __future__ import annotations
 
@@ -35,23 +38,112 @@ def lqr_gain(A: np.ndarray, B: np.ndarray, Q: Optional[np.ndarray] = None, R: Op
     return -np.linalg.solve(R + B.T @ S @ B, B.T @ S @ A)
 
 
+def lmi_point(A: np.ndarray, B: np.ndarray):
+    """(K, X, Z) with X > 0 and [[X, AX+BZ], [(AX+BZ)', X]] > 0, K = Z inv(X): the constraints of reference ``utils.py:47-52``.
+    S solves the discrete Riccati equation with unit weights; X = inv(S) satisfies  X - (A+BK) X (A+BK)' > 0, which is the Schur
+    complement of the block matrix."""
+    from scipy.linalg import solve_discrete_are
+    n, m = B.shape
+    S = solve_discrete_are(A, B, np.eye(n), np.eye(m))
+    K = -np.linalg.solve(np.eye(m) + B.T @ S @ B, B.T @ S @ A)
+    X = np.linalg.inv(S)
+    X = 0.5 * (X + X.T)
+    return K, X, K @ X
+
+
+def compute_control_gain(A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """Stabilising K for the pair (A, B) (reference ``utils.py:43-58``)."""
+    return lmi_point(np.asarray(A, float), np.asarray(B, float))[0]
+
+
+def compute_A_B(Mdata: MatrixZonotope, K: np.ndarray, num_init: int = 10, device: int = 0,
+                rng: Optional[np.random.Generator] = None, beta0: Optional[np.ndarray] = None, max_iter: int = 100):
+    """Adversarial (A, B) for the gain K (reference ``utils.py:13-41``): maximise ||A + B K||_F with the A-columns and the
+    B-columns of every generator of Mdata scaled by independent coefficients in [-1, 1].  ``num_init`` random starting points
+    (or the rows of ``beta0``, S x 2 gamma) are iterated to their fixed points on the GPU; the best one is returned."""
+    from . import native
+    K = np.atleast_2d(np.asarray(K, float))
+    n = K.shape[1]
+    C, G = Mdata.center, Mdata.generators
+    g = G.shape[0]
+    M0 = C[:, :n] + C[:, n:] @ K
+    H = np.concatenate([G[:, :, :n], G[:, :, n:] @ K], axis=0)
+    if beta0 is None:
+        rng = np.random.default_rng() if rng is None else rng
+        beta0 = rng.uniform(-1.0, 1.0, size=(num_init, 2 * g))
+    beta, fro, _ = native.adversary_batch(device, M0, H, beta0, max_iter)
+    b = beta[int(np.argmax(fro))]
+    An = C[:, :n] + np.tensordot(b[:g], G[:, :, :n], axes=(0, 0))
+    Bn = C[:, n:] + np.tensordot(b[g:], G[:, :, n:], axes=(0, 0))
+    return An, Bn
+
+
+def num_robust_samples(accuracy: float, confidence: float) -> int:
+    return int(np.ceil(np.log(1 / confidence) / np.log(1 / (1 - accuracy))))          # reference utils.py:119
+
+
 def is_gain_robust(Mdata: MatrixZonotope, K: np.ndarray, accuracy: float, confidence: float,
-                   rng: Optional[np.random.Generator] = None) -> bool:
+                   rng: Optional[np.random.Generator] = None, device: Optional[int] = None,
+                   beta: Optional[np.ndarray] = None) -> bool:
+    """Reference ``utils.py:105-129``: True iff spectral_radius(A + B K) < 1 for every one of the N samples of Mdata.
+    ``device``: GPU that evaluates the N spectral radii (``tz_specrad_batch``); None: numpy on the host.  ``beta`` (N x gamma)
+    fixes the sample coefficients (tests)."""
+    K = np.atleast_2d(np.asarray(K, float))
     assert K.shape[1] == Mdata.shape[0], "Wrong dimensionality for K"
     assert 0 < accuracy < 1, "Accuracy should be in (0,1)"
     assert 0 < confidence < 1, "confidence should be in (0,1)"
     n = K.shape[1]
-    num = int(np.ceil(np.log(1 / confidence) / np.log(1 / (1 - accuracy))))
-    AB = Mdata.sample(num, rng)
-    Acl = AB[:, :, :n] + AB[:, :, n:] @ K
-    return bool(np.abs(np.linalg.eigvals(Acl)).max() < 1.0)
+    num = num_robust_samples(accuracy, confidence)
+    g = Mdata.num_generators
+    if beta is None:
+        beta = (np.random.uniform(-1.0, 1.0, size=(num, g)) if rng is None else rng.uniform(-1.0, 1.0, size=(num, g)))
+    assert beta.shape == (num, g)
+    if device is None:
+        AB = Mdata.center[None] + np.tensordot(beta, Mdata.generators, axes=(1, 0))
+        return bool(np.abs(np.linalg.eigvals(AB[:, :, :n] + AB[:, :, n:] @ K)).max() < 1.0)
+    from . import native
+    M0 = Mdata.center[:, :n] + Mdata.center[:, n:] @ K
+    H = Mdata.generators[:, :, :n] + Mdata.generators[:, :, n:] @ K
+    rho, status = native.specrad_batch(device, M0, H, beta)
+    if np.any(status != 0):
+        raise RuntimeError("spectral radius: the QR iteration did not converge for %d samples" % int(np.count_nonzero(status)))
+    return bool(not np.any(rho >= 1.0))
 
 
 def compute_theta(Mdata: MatrixZonotope, A0: np.ndarray, B0: np.ndarray, tolerance: float = 1e-5,
                   initial_points: int = 10, max_iterations: int = 20, accuracy: float = 1e-2,
-                  confidence: float = 1e-5, K: Optional[np.ndarray] = None) -> Theta:
-    """Same signature as reference ``utils.py:60``; ``K`` may be supplied (fixture), else LQR."""
-    Kn = lqr_gain(A0, B0) if K is None else np.atleast_2d(np.asarray(K, dtype=float))
-    assert is_gain_robust(Mdata, Kn, accuracy, confidence), \
+                  confidence: float = 1e-5, K: Optional[np.ndarray] = None, synthesize: bool = False,
+                  device: Optional[int] = None, rng: Optional[np.random.Generator] = None, verbose: bool = False) -> Theta:
+    """Same signature as reference ``utils.py:60`` plus: ``K`` (fixture gain), ``synthesize`` (run the reference's alternation
+    ``:72-95`` on GPU ``device``), ``rng``.  Without ``synthesize`` the gain is ``K`` or the LQR gain and the deltas are zero."""
+    if not synthesize:
+        Kn = lqr_gain(A0, B0) if K is None else np.atleast_2d(np.asarray(K, dtype=float))
+        assert is_gain_robust(Mdata, Kn, accuracy, confidence, rng=rng, device=device), \
+            f"K is not robust with accuracy-confidence of {accuracy, 1 - confidence}"
+        return Theta(Kn, np.zeros_like(A0), np.zeros_like(B0))
+    if device is None:
+        raise RuntimeError("compute_theta(synthesize=True) runs the adversarial search and the robustness test on the GPU: pass device=")
+    assert Mdata.contains(np.hstack([A0, B0])), "Mdata does not contain (A0,B0)"
+    n, m = B0.shape
+    rng = np.random.default_rng() if rng is None else rng
+    An, Bn, Kn = A0.copy(), B0.copy(), np.zeros((m, n))
+    prev_lambda_max, iteration, lambda_max = 0.0, 0, np.inf
+    while iteration < max_iterations:                                                   # :72
+        lambda_init = spectral_radius(An + Bn @ Kn)
+        Kn = compute_control_gain(An, Bn)                                               # :74
+        lambda_adv = spectral_radius(An + Bn @ Kn)
+        An, Bn = compute_A_B(Mdata, Kn, initial_points, device=device, rng=rng)         # :78
+        lambda_max = max(spectral_radius(An + Bn @ Kn), spectral_radius(A0 + B0 @ Kn))  # :80
+        if verbose:
+            print(f"[Iteration {iteration}] Closed loop spectral radius: {lambda_init}->{lambda_max} - "
+                  f"Adversarial spectral radius: {lambda_adv} - K {Kn.flatten()}")
+        if np.abs(lambda_max - prev_lambda_max) < tolerance or lambda_max < 1:          # :82
+            break
+        iteration += 1
+        prev_lambda_max = lambda_max
+    # the reference also asserts Mdata.contains([An, Bn]) (:97); with independent coefficients for the A and the B columns
+    # (:26-32) the adversarial pair lies in the interval hull of Mdata but in general NOT in Mdata itself, so that assert can only
+    # hold by accident: the robustness test below is the acceptance criterion kept here
+    assert is_gain_robust(Mdata, Kn, accuracy, confidence, rng=rng, device=device), \
         f"K is not robust with accuracy-confidence of {accuracy, 1 - confidence}"
-    return Theta(Kn, np.zeros_like(A0), np.zeros_like(B0))
+    return Theta(Kn, An - A0, Bn - B0)

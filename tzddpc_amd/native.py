@@ -11,7 +11,7 @@ from typing import Optional
 
 import numpy as np
 
-TZ_ABI_VERSION = 2
+TZ_ABI_VERSION = 3
 TZ_MEM_HOST, TZ_MEM_DEVICE = 0, 1
 TZ_SOLVED, TZ_MAX_ITER, TZ_NUMERICAL, TZ_INFEASIBLE = 0, 1, 2, 3
 
@@ -91,6 +91,10 @@ def lib():
     L.tz_mpc_run.argtypes = [vp, C.c_int32, C.c_int32] + [vp] * 9
     L.tz_identify_batch.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [vp] * 4 + [C.c_int32] + [vp] * 5 + [C.c_int]
     L.tz_identify_batch.restype = C.c_int
+    L.tz_specrad_batch.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
+    L.tz_specrad_batch.restype = C.c_int
+    L.tz_adversary_batch.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp]
+    L.tz_adversary_batch.restype = C.c_int
     L.tz_genstack_create.argtypes = [C.c_int, C.POINTER(GenstackDesc), C.POINTER(vp)]
     L.tz_genstack_destroy.argtypes = [vp]
     L.tz_genstack_intervals.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, C.POINTER(C.c_double), C.c_int]
@@ -118,7 +122,7 @@ def lib():
 EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy",
                     "tz_problem_set_stream", "tz_problem_sync", "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run",
                     "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch",
-                    "tz_problem_set_warm_shift", "tz_problem_reset_warm", "tz_identify_batch",
+                    "tz_problem_set_warm_shift", "tz_problem_reset_warm", "tz_identify_batch", "tz_specrad_batch", "tz_adversary_batch",
                     "tz_genstack_create", "tz_genstack_destroy", "tz_genstack_intervals", "tz_genstack_values", "tz_genstack_info")
 
 
@@ -157,6 +161,32 @@ def identify_batch(device: int, u: np.ndarray, x: np.ndarray, w_center: np.ndarr
     if K is not None:
         out.update(sK=sK, CK=CK)
     return out
+
+
+def specrad_batch(device: int, M0: np.ndarray, H: np.ndarray, beta: np.ndarray):
+    """``tz_specrad_batch``: spectral radius of M0 + sum_i beta[s, i] H[i] for every row s of beta -> (rho (S,), status (S,))."""
+    M0 = np.ascontiguousarray(M0, dtype=np.float64); n = M0.shape[0]
+    H = np.ascontiguousarray(H, dtype=np.float64).reshape(-1, n, n)
+    beta = np.ascontiguousarray(beta, dtype=np.float64).reshape(-1, H.shape[0])
+    S = beta.shape[0]
+    rho = np.empty(S); status = np.empty(S, dtype=np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib().tz_specrad_batch(int(device), S, n, H.shape[0], vp(M0), vp(H), vp(beta), vp(rho), vp(status)), "tz_specrad_batch")
+    return rho, status
+
+
+def adversary_batch(device: int, M0: np.ndarray, H: np.ndarray, beta0: np.ndarray, max_iter: int = 100):
+    """``tz_adversary_batch``: CCP ascent of ||M0 + sum_i beta_i H_i||_F over the box from every row of beta0
+    -> (beta (S, ngen) fixed points, fro (S,), steps (S,))."""
+    M0 = np.ascontiguousarray(M0, dtype=np.float64); n = M0.shape[0]
+    H = np.ascontiguousarray(H, dtype=np.float64).reshape(-1, n, n)
+    beta0 = np.ascontiguousarray(beta0, dtype=np.float64).reshape(-1, H.shape[0])
+    S = beta0.shape[0]
+    beta = np.empty_like(beta0); fro = np.empty(S); steps = np.empty(S, dtype=np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib().tz_adversary_batch(int(device), S, n, H.shape[0], vp(M0), vp(H), vp(beta0), int(max_iter), vp(beta), vp(fro), vp(steps)),
+          "tz_adversary_batch")
+    return beta, fro, steps
 
 
 def _f64(a):

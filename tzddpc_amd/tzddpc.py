@@ -130,27 +130,35 @@ class TZDDPC(object):
 
     # ---- reference :87-93 ------------------------------------------------------------------------
     def compute_theta(self, tol: float = 1e-5, num_max_iterations: int = 20, num_initial_points: int = 10,
-                      K: Optional[np.ndarray] = None) -> Theta:
+                      K: Optional[np.ndarray] = None, synthesize: bool = False, rng=None) -> Theta:
+        """``synthesize=True``: the reference's gain synthesis (``tzddpc/utils.py:60-103``) with its adversarial search and
+        robustness test on this controller's GPU; default: ``K`` or the LQR gain of the identified model (deltas zero)."""
         assert self.Mdata is not None, "Mdata is not defined"
         n = self.dim_x
         self.theta = _compute_theta(self.Mdata, self.Mdata.center[:, :n], self.Mdata.center[:, n:],
-                                    tol, num_initial_points, num_max_iterations, K=K)
+                                    tol, num_initial_points, num_max_iterations, K=K, synthesize=synthesize,
+                                    device=self.device if synthesize else None, rng=rng)
         return self.theta
 
     # ---- reference :95-130 -----------------------------------------------------------------------
     def build_zonotopes_theta(self, zonotopes: SystemZonotopes, tol: float = 1e-5, num_max_iterations: int = 20,
                               num_initial_points: int = 10, theta: Optional[Theta] = None,
-                              K: Optional[np.ndarray] = None, device: bool = False) -> Tuple[Theta, MatrixZonotope]:
+                              K: Optional[np.ndarray] = None, device: bool = False, synthesize: bool = False,
+                              rng=None) -> Tuple[Theta, MatrixZonotope]:
         """As the reference, plus ``theta=`` / ``K=`` to supply the gain as a fixture (the reference's
         LMI + DCCP/MOSEK synthesis, ``tzddpc/utils.py:60-103``, is out of scope; default is LQR) and ``device=True``:
-        the identification (Gram / pinv contraction, boxed magnitudes) runs on the GPU (``tz_identify_batch``, kernel K0)."""
+        the identification (Gram / pinv contraction, boxed magnitudes) runs on the GPU (``tz_identify_batch``, kernel K0).
+        ``synthesize=True`` runs the reference's gain synthesis (``tzddpc/utils.py:60-103``, on the un-reduced Mdata as in
+        ``:114``) with the adversarial search and the robustness test on the GPU; the deltas of the returned Theta are then the
+        adversarial model errors ``solve_simplified2`` uses."""
         if device:
+            assert not synthesize, "the device identification returns the boxed Mdata only; the synthesis needs the un-reduced one"
             return self._build_zonotopes_theta_device(zonotopes, tol, num_max_iterations, num_initial_points, theta, K)
         self.build_zonotopes(zonotopes)
         if theta is not None:
             self.theta = Theta(np.atleast_2d(np.asarray(theta.K, float)), theta.deltaA, theta.deltaB)
         else:
-            self.compute_theta(tol, num_max_iterations, num_initial_points, K=K)
+            self.compute_theta(tol, num_max_iterations, num_initial_points, K=K, synthesize=synthesize, rng=rng)
         n = self.dim_x
         self.MdataK = self.Mdata * np.vstack([np.eye(n), self.theta.K])                    # :119
         self.Mdelta = self.Mdata + (-1.0 * self.Mdata.center)                               # :122-123
