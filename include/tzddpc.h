@@ -114,6 +114,13 @@ typedef struct tz_problem_desc {
   const int32_t* shift_row;     /* mi */
   const double* shift_xscale;   /* nz */
   const double* shift_lscale;   /* mi */
+  /* recovery of v when the host has eliminated equality constraints of build_constraints (reference tzddpc/tzddpc.py:213-219
+   * accepts any DCP constraint, `==` included): the first N m variables are then no longer v itself and
+   *     v = rec_c0 + rec_x0 xbar0 + rec_y x          (N m; N m x n; N m x nz, x the SCALED variables: Dz is folded in)
+   * replaces v = Dz .* x[:N m].  All three NULL: no elimination. */
+  const double* rec_c0;
+  const double* rec_x0;
+  const double* rec_y;
 } tz_problem_desc;
 
 typedef struct tz_problem tz_problem;

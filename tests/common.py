@@ -33,6 +33,10 @@ def nocons(u, x):
     return []
 
 
+def cons_di_eq(v, x):         # `==` rows (reference tzddpc/tzddpc.py:213-219 takes any DCP constraint): terminal state, move blocking
+    return [x[x.shape[0] - 1, :] == np.array([-4.0, 0.0]), v[3] == v[4], v[5, 0] <= 0.9]
+
+
 CASES = {
     # name: (system, loss, constraints, horizon, k0)
     "di_n2": ("di_sim", loss_di, nocons, 2, None),
@@ -44,6 +48,7 @@ CASES = {
     "di_n20_k1": ("di_cc", loss_di, nocons, 20, 1),
     "di_n10": ("di_cc", loss_di, nocons, 10, None),
     "di_n40": ("di_cc", loss_di, nocons, 40, None),
+    "di_n10_eq": ("di_cc", loss_di, cons_di_eq, 10, None),
     "pulley_n10": ("pulley", loss_pulley, nocons, 10, None),
     "dim5_n20": ("dim5_w001", loss_dim5, cons_dim5, 20, None),
 }

@@ -667,3 +667,77 @@ def test_compute_theta_synthesis_matches_oracle(built):
     theta, _ = ctl.build_zonotopes_theta(zon, synthesize=True, rng=np.random.default_rng(11))
     assert PG.spectral_radius(ctl.Mdata.center[:, :n] + ctl.Mdata.center[:, n:] @ theta.K) < 1
     assert theta.deltaA.shape == (2, 2) and theta.deltaB.shape == (2, 1) and np.abs(theta.deltaB).max() > 0
+
+
+# ---- user equality constraints (reference tzddpc/tzddpc.py:213-219) ---------------------------------------------------------------
+def test_user_equality_constraints_match_oracle(built):
+    """`==` rows from build_constraints (terminal state, move blocking) are eliminated on the host and v is recovered on the
+    device through an affine map: solve_batch against the oracle's interior point on the two-sided problem WITH its equality rows
+    (cost, v, xbar, the equalities themselves), and the fused closed loop against a host loop of oracle solves."""
+    ctl, (A, B, zon) = common.gpu_controller("di_n10_eq")
+    qp = ctl.qp
+    assert ctl._elim is not None and len(ctl._elim.eq_rows) == 3
+    x0, e0 = common.sample_params(zon, 2, 6)
+    out = ctl.solve_batch(x0, e0, want_active=True)
+    assert (out["status"] == 0).all(), out["status"]
+    for b in range(6):
+        o = common.oracle_solution(qp, x0[b], e0[b])
+        assert o["status"] == "solved"
+        assert abs(out["cost"][b] - o["cost"]) <= 1e-7 * (1 + abs(o["cost"]))
+        np.testing.assert_allclose(out["v"][b], o["v"], atol=REL * (1 + np.abs(o["v"]).max()))
+        np.testing.assert_allclose(out["xbar"][b], o["xbar"], atol=REL * (1 + np.abs(o["xbar"]).max()))
+        np.testing.assert_allclose(out["xbar"][b, -1], [-4.0, 0.0], atol=1e-9)            # terminal equality
+        assert abs(out["v"][b, 3, 0] - out["v"][b, 4, 0]) <= 1e-10                           # move blocking
+        assert out["active"][b, ctl._elim.eq_rows].all()
+    # reference-shaped single solve
+    res, v, xbar, _ = ctl.solve(x0[1], e0[1])
+    assert abs(res - out["cost"][1]) <= 1e-9 * (1 + abs(res))
+    # closed loop (fused kernel, recovery map inside the epilogue) against a host loop of oracle solves
+    Bn, T = 4, 5
+    Wv = zon.W.compute_vertices()
+    noise = Wv[np.random.default_rng(5).integers(0, Wv.shape[0], size=(Bn, T))]
+    xs = np.tile(zon.X0.center, (Bn, 1))
+    sim = ctl.simulate_batch(xs, noise, A, B)
+    assert (sim["status"] == 0).all()
+    K = ctl.theta.K
+    for b in range(Bn):
+        x = xs[b].copy(); xbar = x.copy(); e = np.zeros(2)
+        for t in range(T):
+            o = common.oracle_solution(qp, xbar, e)
+            assert o["status"] == "solved"
+            u = o["v"][0] + K @ e
+            np.testing.assert_allclose(sim["u"][b, t], u, atol=REL * (1 + np.abs(u).max()))
+            x = A @ x + B @ u + noise[b, t]
+            xbar = o["xbar"][1]; e = x - xbar
+            np.testing.assert_allclose(sim["x"][b, t + 1], x, atol=REL * (1 + np.abs(x).max()))
+
+
+def test_user_equality_constraints_independent_chain(built):
+    """The same problem assembled by the ORACLE alone (oracle/collapsed.py with the equality rows as extra rows, its own
+    identification) -- nothing of the product's builder or elimination in the expected values."""
+    from oracle import collapsed as OC, harness as H
+    from oracle.qp_ipm import solve_qp
+    ctl, (A, B, zon) = common.gpu_controller("di_n10_eq")
+    d = ctl.dataset.original_data
+    s = H.system("di_cc")
+    idn = H.identify(np.asarray(d.u, float), np.asarray(d.x, float), s["W"], K=ctl.theta.K)
+    N = 10
+
+    def extra(nxi, x_idx, v_idx):
+        rows = []
+        for i, tgt in enumerate((-4.0, 0.0)):
+            a = np.zeros(nxi); a[x_idx[N, i]] = 1.0; rows.append((a, tgt, tgt))
+        a = np.zeros(nxi); a[v_idx[3, 0]] = 1.0; a[v_idx[4, 0]] = -1.0; rows.append((a, 0.0, 0.0))
+        a = np.zeros(nxi); a[v_idx[5, 0]] = 1.0; rows.append((a, -np.inf, 0.9))
+        return rows
+    x0, e0 = common.sample_params(zon, 2, 4)
+    out = ctl.solve_batch(x0, e0)
+    for b in range(4):
+        q = OC.build_collapsed(idn["A"], idn["B"], idn["MdataK"], idn["Mdelta"], idn["K"], s["W"], s["X"], s["U"], N, e0[b], x0[b],
+                               H.loss_di, extra)
+        r = solve_qp(q["P"], q["q"], q["A"], q["l"], q["u"], tol=1e-12)
+        assert r.status == "solved"
+        vv, xb = OC.extract(q, r.x)
+        assert abs(out["cost"][b] - (r.obj + q["r"])) <= 1e-7 * (1 + abs(r.obj + q["r"]))
+        np.testing.assert_allclose(out["v"][b], np.asarray(vv).reshape(N, 1), atol=REL * (1 + np.abs(vv).max()))
+        np.testing.assert_allclose(out["xbar"][b], np.asarray(xb).reshape(N + 1, 2), atol=REL * (1 + np.abs(xb).max()))

@@ -191,3 +191,28 @@ def test_horizon_shift_maps():
     rows = qp.row_names
     assert rows[sr[rows.index("Xub[4,1]")]] == "Xub[5,1]" and rows[sr[rows.index("tau[3]+-+")]] == "tau[4]+-+"
     assert len(set(sv.tolist())) == len(sv) - 2           # only the two last-step variables are the target of two sources
+
+
+def test_equality_elimination_preserves_the_optimum():
+    """builder.eliminate_equalities: the reduced inequality-only problem the device solves has the optimum of the two-sided problem
+    with its `==` rows (oracle interior point on both), v comes back through x = x0 + Xn xbar0 + Z y, rows that lose all their
+    coefficients turn into parameter tests, and problems without equality rows pass through untouched."""
+    from oracle.qp_ipm import solve_qp
+    from tzddpc_amd.builder import eliminate_equalities, theta_reference
+    ctl, qp, (A, B, zon) = common.identified_qp("di_n10_eq")
+    red, el = eliminate_equalities(qp)
+    assert len(el.eq_rows) == 3 and red.nz == max(qp.nz - 3, qp.N * qp.m) and red.nc + len(el.eq_rows) <= qp.nc
+    nv = qp.N * qp.m
+    x0s, e0s = common.sample_params(zon, 2, 3)
+    for b in range(3):
+        o = common.oracle_solution(qp, x0s[b], e0s[b])
+        th = theta_reference(qp, x0s[b], e0s[b])
+        r = solve_qp(red.P, red.q0 + red.Qt @ th, red.A, red.l0 + red.Lt @ th, red.u0 + red.Ut @ th, tol=1e-12)
+        assert o["status"] == "solved" == r.status
+        x = el.x0 + el.Xn @ x0s[b] + el.Z @ r.x
+        cost = r.obj + red.r0 + red.r1 @ x0s[b] + x0s[b] @ red.R2 @ x0s[b]
+        assert abs(cost - o["cost"]) <= 1e-7 * (1 + abs(o["cost"]))
+        np.testing.assert_allclose(x[:nv], o["v"].ravel(), atol=1e-7)
+        np.testing.assert_allclose(qp.A[el.eq_rows] @ x, qp.u0[el.eq_rows] + qp.Ut[el.eq_rows] @ th, atol=1e-10)
+    same, none = eliminate_equalities(common.identified_qp("di_n5")[1])
+    assert none is None and same.nz == same.P.shape[0]

@@ -501,6 +501,80 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
                         tube=tube, row_names=[r[0] for r in qp_rows], var_names=var_names, n_v=N * m)
 
 
+@dataclass
+class Elimination:
+    """x = x0 + Xn xbar0 + Z y : the equality rows of the two-sided problem solved for `basic` variables (QR with column
+    pivoting); y are the remaining variables in their original order (+ `npad` dummies so that there are at least N m)."""
+    x0: np.ndarray          # nz
+    Xn: np.ndarray          # nz x n
+    Z: np.ndarray           # nz x ny
+    free: np.ndarray        # original index of y_k (-1 for the dummies)
+    eq_rows: np.ndarray     # rows of the original problem that were equalities
+    keep_rows: np.ndarray   # rows of the original problem that stay rows of the reduced one (in that order)
+
+
+def eliminate_equalities(qp: ParametricQP):
+    """User `==` constraints (reference ``tzddpc/tzddpc.py:213-219`` accepts them like any DCP constraint): the interior-point
+    kernel works on inequality rows only, so equality rows  E x = f0 + Ft theta  are eliminated on the host at build time.
+    Returns (reduced ParametricQP, Elimination) or (qp, None) when there is no equality row."""
+    from scipy.linalg import qr, solve_triangular
+    fu, fl = np.isfinite(qp.u0), np.isfinite(qp.l0)
+    eq = fu & fl & (qp.u0 == qp.l0) & np.all(qp.Ut == qp.Lt, axis=1)
+    if not np.any(eq):
+        return qp, None
+    n, nz, nth = qp.n, qp.nz, qp.ntheta
+    E, f0, Ft = qp.A[eq], qp.u0[eq], qp.Ut[eq]
+    if np.any(Ft[:, n:]) or np.any(qp.Qt[:, n:]):
+        raise NotImplementedError("equality constraints whose right-hand side depends on the tube parameters are not supported")
+    Q, R, piv = qr(E, pivoting=True)
+    d = np.abs(np.diag(R)) if R.size else np.zeros(0)
+    rank = int(np.count_nonzero(d > max(E.shape) * np.finfo(float).eps * (d[0] if d.size else 1.0)))
+    rhs = Q.T @ np.hstack([f0[:, None], Ft[:, :n]])
+    if rank < E.shape[0] and np.abs(rhs[rank:]).max(initial=0.0) > 1e-9 * (1.0 + np.abs(rhs).max()):
+        raise Exception("Constraint rows from build_constraints are linearly dependent with inconsistent right-hand sides")
+    basic, free = piv[:rank], np.sort(piv[rank:])
+    R1 = R[:rank, :rank]
+    col_of = {int(c): i for i, c in enumerate(piv[rank:])}
+    T = solve_triangular(R1, R[:rank, rank:][:, [col_of[int(c)] for c in free]]) if free.size else np.zeros((rank, 0))
+    sol = solve_triangular(R1, rhs[:rank])
+    npad = max(0, qp.N * qp.m - free.size)
+    ny = free.size + npad
+    Z = np.zeros((nz, ny)); Z[free, np.arange(free.size)] = 1.0; Z[basic, :free.size] = -T
+    x0 = np.zeros(nz); x0[basic] = sol[:, 0]
+    Xn = np.zeros((nz, n)); Xn[basic] = sol[:, 1:]
+    Xt = np.zeros((nz, nth)); Xt[:, :n] = Xn
+    Qn = qp.Qt[:, :n]
+    P2 = Z.T @ qp.P @ Z
+    q02 = Z.T @ (qp.P @ x0 + qp.q0)
+    Qt2 = Z.T @ (qp.P @ Xt + qp.Qt)
+    r0 = qp.r0 + 0.5 * x0 @ qp.P @ x0 + qp.q0 @ x0
+    r1 = qp.r1 + Xn.T @ (qp.P @ x0 + qp.q0) + Qn.T @ x0
+    R2 = qp.R2 + 0.5 * Xn.T @ qp.P @ Xn + Qn.T @ Xn
+    # inequality rows; those that lose all their coefficients become parameter tests
+    rest = np.nonzero(~eq)[0]
+    A2 = qp.A[rest] @ Z
+    sh0 = qp.A[rest] @ x0; sht = qp.A[rest] @ Xt
+    l02, Lt2 = qp.l0[rest] - sh0, qp.Lt[rest] - sht
+    u02, Ut2 = qp.u0[rest] - sh0, qp.Ut[rest] - sht
+    scale = np.abs(qp.A[rest]).max(axis=1, initial=0.0) * (1.0 + np.abs(Z).max(initial=0.0))
+    A2[np.abs(A2) <= 1e-13 * np.maximum(scale, 1e-300)[:, None]] = 0.0
+    live = np.any(A2 != 0.0, axis=1)
+    f0p, Ftp, plp, pup = [qp.f0], [qp.Ft], [qp.pl], [qp.pu]
+    for i in np.nonzero(~live)[0]:                       # need l0 + Lt theta <= 0 <= u0 + Ut theta
+        if np.isfinite(l02[i]):
+            f0p.append([l02[i]]); Ftp.append(Lt2[i][None]); plp.append([-np.inf]); pup.append([0.0])
+        if np.isfinite(u02[i]):
+            f0p.append([u02[i]]); Ftp.append(Ut2[i][None]); plp.append([0.0]); pup.append([np.inf])
+    names = [qp.var_names[i] for i in free] + [f"pad[{i}]" for i in range(npad)]
+    red = ParametricQP(n=n, m=qp.m, N=qp.N, nz=ny, nc=int(live.sum()), ntheta=nth, P=0.5 * (P2 + P2.T), A=A2[live],
+                       q0=q02, Qt=Qt2, l0=l02[live], Lt=Lt2[live], u0=u02[live], Ut=Ut2[live],
+                       f0=np.concatenate(f0p), Ft=np.vstack(Ftp), pl=np.concatenate(plp), pu=np.concatenate(pup),
+                       r0=float(r0), r1=r1, R2=R2, Phi=qp.Phi, Gam=qp.Gam, tube=qp.tube,
+                       row_names=[qp.row_names[i] for i in rest[live]], var_names=names, n_v=qp.n_v)
+    free_idx = np.concatenate([free, -np.ones(npad, dtype=free.dtype)])
+    return red, Elimination(x0=x0, Xn=Xn, Z=Z, free=free_idx, eq_rows=np.nonzero(eq)[0], keep_rows=rest[live])
+
+
 def horizon_shift(qp: ParametricQP):
     """Receding-horizon shift of a solution: entry c of the first array is the variable whose previous value is the starting
     guess of variable c one MPC step later (``v[k,i] <- v[k+1,i]``, ``tau[j] <- tau[j+1]`` ...; the last step keeps its own),

@@ -1442,6 +1442,14 @@ retry_solve:
     const bool want_cost = F.cost_step != 0 || step == nsteps - 1;      // a cost that the next step overwrites is not formed
     __syncthreads();
     if (want_cost && !px_in_part) tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
+    if (F.fin.recy) {                                    // equality rows eliminated by the host: v is an affine map of (xbar0, x)
+      for (int c = t; c < nv; c += TZ_THREADS) {
+        double a = F.fin.rec0[c];
+        for (int j = 0; j < n; ++j) a += F.fin.recx[(size_t)c * n + j] * x0[j];
+        for (int k = 0; k < nz; ++k) a += F.fin.recy[(size_t)c * nz + k] * xv[k];
+        dxv[c] = a;
+      }
+    } else
     for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = cDz[c] * xv[F.fin.vpos ? F.fin.vpos[c] : c];     // v in the caller's order
     __syncthreads();
     double acc = 0.0, z1 = 0.0, z2 = 0.0;

@@ -158,6 +158,7 @@ struct FinishParams {
   double* v; double* xbar; double* cost; uint8_t* active;   // active may be null
   size_t cost_stride;
   const int* vpos;       // device position of v[k, j] in x (staircase ordering of the library); null = identity
+  const double* rec0; const double* recx; const double* recy;   // equality-eliminated problems: v = rec0 + recx xbar0 + recy x (recy in device column order), else null
 };
 
 struct PlantParams {
@@ -221,13 +222,23 @@ __global__ __launch_bounds__(64) void tz_finish_kernel(FinishParams p) {
     p.cost[(size_t)b * p.cost_stride] = (st == 0) ? acc / p.cost_scale + r : INFINITY;
   }
   double* v = p.v + (size_t)b * nv;
-  for (int c = lane; c < nv; c += 64) v[c] = p.Dz[c] * x[p.vpos ? p.vpos[c] : c];
+  for (int c = lane; c < nv; c += 64) {
+    if (p.recy) {
+      double a = p.rec0[c];
+      for (int j = 0; j < n; ++j) a += p.recx[(size_t)c * n + j] * x0[j];
+      for (int k = 0; k < nz; ++k) a += p.recy[(size_t)c * nz + k] * x[k];
+      v[c] = a;
+    } else {
+      v[c] = p.Dz[c] * x[p.vpos ? p.vpos[c] : c];
+    }
+  }
+  __syncthreads();                                       // one wave: orders the stores of v above before the loads below
   double* xb = p.xbar + (size_t)b * (N + 1) * n;
   for (int r = lane; r < (N + 1) * n; r += 64) {
     double a = 0.0;
     for (int j = 0; j < n; ++j) a += p.Phi[(size_t)r * n + j] * x0[j];
     const double* g = p.Gam + (size_t)r * nv;
-    for (int c = 0; c < nv; ++c) a += g[c] * (p.Dz[c] * x[p.vpos ? p.vpos[c] : c]);
+    for (int c = 0; c < nv; ++c) a += g[c] * v[c];
     xb[r] = a;
   }
   if (p.active) {

@@ -150,7 +150,7 @@ struct tz_problem {
   int max_iter = 40;
   double tol = 1e-10, reg = 1e-12, step_frac = 0.99, cost_scale = 1.0, r0 = 0.0;
   // constants
-  DevBuf<double> P, G, Gt, Gp, act_scale, Dz, Phi, Gam, r1, R2, CK, DK, K, CKpow, Ttube, par_lo, par_hi;
+  DevBuf<double> P, G, Gt, Gp, act_scale, Dz, Phi, Gam, r1, R2, CK, DK, K, CKpow, Ttube, par_lo, par_hi, rec0, recx, recy;
   DevBuf<int> power, row_of, klist, item_ptr, smask, shift_var, shift_row;
   DevBuf<double> shift_xs, shift_ls;
   int shift_policy = 0;        // 0 never, 1 always, k >= 2: after a step of >= k iterations (tz_problem_set_warm_shift)
@@ -304,7 +304,8 @@ int launch_step_fused(tz_problem* p, int B, double* d_x, double* d_xbar, double*
   F.qmap = p->q.view(); F.hmap = p->h.view(); F.parmap = p->par.view(); F.par_lo = p->par_lo.p; F.par_hi = p->par_hi.p;
   F.fin = FinishParams{B, p->n, p->m, p->N, p->nz, p->mi, p->nzp, p->nc_rows, p->P.p, p->Dz.p, p->Phi.p, p->Gam.p,
                        p->r1.p, p->R2.p, p->r0, p->cost_scale, p->row_of.p, p->act_scale.p, d_xbar, nullptr, nullptr, nullptr, nullptr,
-                       d_status, nsteps > 1 ? nullptr : p->v.p, nsteps > 1 ? nullptr : p->xbar.p, d_cost, nullptr, cost_stride, p->vpos.p};
+                       d_status, nsteps > 1 ? nullptr : p->v.p, nsteps > 1 ? nullptr : p->xbar.p, d_cost, nullptr, cost_stride, p->vpos.p,
+                       p->rec0.p, p->recx.p, p->recy.p};
   F.plant = PlantParams{B, p->n, p->m, p->N, p->K.p, d_A, d_Bm, nullptr, nullptr, d_w, w_stride, d_status, d_x, d_xbar, d_e,
                         d_u, u_stride, d_xout, x_stride, d_sticky};
   hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, p->stream, ip);
@@ -336,7 +337,7 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
     Timer tm(p, K_FINISH);
     FinishParams fp{B, p->n, p->m, p->N, p->nz, p->mi, p->nzp, p->nc_rows, p->P.p, p->Dz.p, p->Phi.p, p->Gam.p,
                     p->r1.p, p->R2.p, p->r0, p->cost_scale, p->row_of.p, p->act_scale.p, d_xbar0, p->qv.p, p->x.p, p->s.p, p->lam.p,
-                    d_status, d_v, d_xbar, d_cost, d_active, cost_stride, p->vpos.p};
+                    d_status, d_v, d_xbar, d_cost, d_active, cost_stride, p->vpos.p, p->rec0.p, p->recx.p, p->recy.p};
     hipLaunchKernelGGL(tz_finish_kernel, dim3(B), dim3(64), 0, st, fp);
   }
   TZ_HIP(hipGetLastError());
@@ -748,6 +749,12 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   TZ_HIP(p->q.upload(d->q, permc.data())); TZ_HIP(p->h.upload(d->h, permr.data())); TZ_HIP(p->par.upload(d->par));
   TZ_HIP(p->par_lo.upload(d->par_lo, (size_t)p->npar)); TZ_HIP(p->par_hi.upload(d->par_hi, (size_t)p->npar));
   TZ_HIP(p->Dz.upload(d->Dz, (size_t)nz));
+  if (d->rec_y || d->rec_c0 || d->rec_x0) {                              // equality-eliminated problem: affine recovery of v
+    if (!(d->rec_y && d->rec_c0 && d->rec_x0)) TZ_FAIL(TZ_ERR_INVALID, "rec_c0, rec_x0 and rec_y go together");
+    std::vector<double> ry((size_t)nv * nz);
+    for (int c = 0; c < nv; ++c) for (int k = 0; k < nz; ++k) ry[(size_t)c * nz + k] = d->rec_y[(size_t)c * nz + permc[k]];
+    TZ_HIP(p->recy.upload(ry)); TZ_HIP(p->rec0.upload(d->rec_c0, (size_t)nv)); TZ_HIP(p->recx.upload(d->rec_x0, (size_t)nv * d->n));
+  }
   TZ_HIP(p->Phi.upload(d->Phi, (size_t)(d->N + 1) * d->n * d->n));
   TZ_HIP(p->Gam.upload(d->Gam, (size_t)(d->N + 1) * d->n * d->N * d->m));
   TZ_HIP(p->r1.upload(d->r1, (size_t)d->n)); TZ_HIP(p->R2.upload(d->R2, (size_t)d->n * d->n));

@@ -44,6 +44,7 @@ class ProblemDesc(C.Structure):
         ("CK", _dp), ("DK", _dp), ("K", _dp), ("pmax", C.c_int32), ("absCKpow", _dp), ("absKCKpow", _dp), ("power", _ip),
         ("max_iter", C.c_int32), ("tol", C.c_double), ("reg", C.c_double), ("step_frac", C.c_double),
         ("shift_var", _ip), ("shift_row", _ip), ("shift_xscale", _dp), ("shift_lscale", _dp),
+        ("rec_c0", _dp), ("rec_x0", _dp), ("rec_y", _dp),
     ]
 
 
@@ -226,7 +227,7 @@ class Problem:
     def __init__(self, device: int, *, n, m, N, P, G, q0, Qt, h0, Ht, par0, Part, par_lo, par_hi, cost_scale, r0, r1, R2,
                  Dz, Phi, Gam, nc_rows, row_of, act_scale, CK, DK, K, pmax, absCKpow, absKCKpow, power,
                  max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999,
-                 shift_var=None, shift_row=None, shift_xscale=None, shift_lscale=None):
+                 shift_var=None, shift_row=None, shift_xscale=None, shift_lscale=None, rec_c0=None, rec_x0=None, rec_y=None):
         L = lib()
         keep = []
         d = ProblemDesc()
@@ -252,6 +253,10 @@ class Problem:
             sv, sr, xs, ls = _i32(shift_var), _i32(shift_row), _f64(shift_xscale), _f64(shift_lscale)
             keep += [sv, sr, xs, ls]
             d.shift_var = _ptr(sv, _ip); d.shift_row = _ptr(sr, _ip); d.shift_xscale = _ptr(xs, _dp); d.shift_lscale = _ptr(ls, _dp)
+        if rec_y is not None:
+            rc, rx, ry = _f64(rec_c0).reshape(N * m), _f64(rec_x0).reshape(N * m, n), _f64(rec_y).reshape(N * m, d.nz)
+            keep += [rc, rx, ry]
+            d.rec_c0 = _ptr(rc, _dp); d.rec_x0 = _ptr(rx, _dp); d.rec_y = _ptr(ry, _dp)
         self.n, self.m, self.N, self.nz, self.mi, self.nc_rows, self.ntheta = int(n), int(m), int(N), d.nz, d.mi, int(nc_rows), d.ntheta
         # structure-aware algorithmic work of one interior-point factorisation + its two solves (what bench.py's roofline
         # counts): sparse outer products of the rows of G, Cholesky, four G / G' products, two triangular solve pairs, P x

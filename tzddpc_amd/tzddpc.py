@@ -227,11 +227,14 @@ class TZDDPC(object):
         self.qp = qp
         self.horizon = int(horizon)
         self.k0 = k0
+        # `==` rows of build_constraints (reference :213-219) are eliminated here: the kernel sees inequality rows only and
+        # recovers v through an affine map (self.qp stays the two-sided problem with its equality rows)
+        from .builder import eliminate_equalities
+        qp, elim = eliminate_equalities(qp)
+        self._elim = elim
+        rec = {}
         # one-sided, equilibrated form for the interior-point kernel
         fu = np.isfinite(qp.u0); fl = np.isfinite(qp.l0)
-        eq = fu & fl & (qp.u0 == qp.l0) & np.all(qp.Ut == qp.Lt, axis=1)
-        if np.any(eq):
-            raise NotImplementedError("equality constraints from build_constraints are not supported by the HIP solver yet")
         G = np.vstack([qp.A[fu], -qp.A[fl]])
         h0 = np.concatenate([qp.u0[fu], -qp.l0[fl]])
         Ht = np.vstack([qp.Ut[fu], -qp.Lt[fl]])
@@ -239,6 +242,14 @@ class TZDDPC(object):
         q_ref = np.abs(qp.q0) + np.abs(qp.Qt).sum(axis=1)
         D, E, c = _ruiz(qp.P, G, q_ref)
         self._scal = (D, E, c)
+        nc_rows = qp.nc
+        if elim is not None:
+            nv = int(horizon) * m
+            rec = dict(rec_c0=elim.x0[:nv], rec_x0=elim.Xn[:nv], rec_y=elim.Z[:nv] * D[None, :])
+            nc_rows = self.qp.nc
+        row_red = row_of                                                  # rows of the (reduced) problem the kernel works on
+        if elim is not None:
+            row_of = elim.keep_rows[row_of].astype(np.int32)              # ... and of the problem the caller sees (self.qp)
         self._row_of = row_of
         # receding-horizon shift of the warm start (maps only; whether it is used is decided below)
         from .builder import horizon_shift
@@ -246,7 +257,7 @@ class TZDDPC(object):
         pos = {(int(r), 0): k for k, r in enumerate(np.nonzero(fu)[0])}
         pos.update({(int(r), 1): k + int(fu.sum()) for k, r in enumerate(np.nonzero(fl)[0])})
         side = np.concatenate([np.zeros(int(fu.sum()), int), np.ones(int(fl.sum()), int)])
-        sr = np.array([pos.get((int(sr2[row_of[k]]), int(side[k])), k) for k in range(len(row_of))], dtype=np.int32)
+        sr = np.array([pos.get((int(sr2[row_red[k]]), int(side[k])), k) for k in range(len(row_red))], dtype=np.int32)
         shift = dict(shift_var=sv.astype(np.int32), shift_row=sr, shift_xscale=D[sv] / D, shift_lscale=E[sr] / E)
         warm_shift = solver_kwargs.pop("warm_shift", "auto")
         opts = dict(max_iter=int(solver_kwargs.pop("max_iter", 40)), tol=float(solver_kwargs.pop("tol", 1e-10)),
@@ -258,7 +269,7 @@ class TZDDPC(object):
             q0=c * D * qp.q0, Qt=(c * D)[:, None] * qp.Qt, h0=E * h0, Ht=E[:, None] * Ht,
             par0=qp.f0, Part=qp.Ft, par_lo=qp.pl, par_hi=qp.pu,
             cost_scale=c, r0=qp.r0, r1=qp.r1, R2=qp.R2, Dz=D, Phi=qp.Phi, Gam=qp.Gam,
-            nc_rows=qp.nc, row_of=row_of, act_scale=c / (E * E),
+            nc_rows=nc_rows, row_of=row_of, act_scale=c / (E * E), **rec,
             CK=qp.tube.CK, DK=qp.tube.DK, K=qp.tube.K, pmax=qp.tube.pmax,
             absCKpow=qp.tube.absCKpow, absKCKpow=qp.tube.absKCKpow, power=qp.tube.power, **shift, **opts)
         self.warm_shift_policy = self._choose_warm_shift(warm_shift, A, B)
@@ -380,6 +391,8 @@ class TZDDPC(object):
         v, xbar, cost, status, iters, active = self._native.solve_batch(xbar0, e0, want_active)
         out = dict(cost=cost, v=v, xbar=xbar, status=status, iters=iters)
         if want_active:
+            if getattr(self, "_elim", None) is not None:
+                active[:, self._elim.eq_rows] = 1          # eliminated equality rows hold with equality by construction
             out["active"] = active
         if want_ze1:
             out["ze1"] = self.ze1_batch(xbar0, e0, v[:, 0])
