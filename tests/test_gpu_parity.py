@@ -741,3 +741,56 @@ def test_user_equality_constraints_independent_chain(built):
         assert abs(out["cost"][b] - (r.obj + q["r"])) <= 1e-7 * (1 + abs(r.obj + q["r"]))
         np.testing.assert_allclose(out["v"][b], np.asarray(vv).reshape(N, 1), atol=REL * (1 + np.abs(vv).max()))
         np.testing.assert_allclose(out["xbar"][b], np.asarray(xb).reshape(N + 1, 2), atol=REL * (1 + np.abs(xb).max()))
+
+
+# ---- solve_simplified2 (reference tzddpc/tzddpc.py:381-500) ----------------------------------------------
+@pytest.mark.parametrize("name,ze_sum", [("di", "radius"), ("di", "columns"), ("pulley", "radius")])
+def test_solve_simplified2_matches_oracle(built, name, ze_sum):
+    """Device solve of the condensed, equality-eliminated problem against the oracle's literal restatement (every variable and
+    constraint of the reference kept, oracle interior point): result, v, xbar, ubar, Ze[1]; reference-shaped returns and errors."""
+    from oracle import simplified2 as S2
+    from tests.test_oracle_simplified2 import params, problem_data
+    from tzddpc_amd import TZDDPC, Data, SystemZonotopes, Theta, Zonotope
+    d = problem_data(name)
+    s, idn, N = d["s"], d["idn"], d["N"]
+    zon = SystemZonotopes(*(Zonotope(np.asarray(s[k].center), np.asarray(s[k].generators)) for k in ("X0", "U", "X", "W")))
+    ctl = TZDDPC(Data(d["u"], d["x"]))
+    ctl.build_zonotopes_theta(zon, theta=Theta(idn["K"], d["dA"], d["dB"]))
+    Zs = [Zonotope(np.asarray(Z.center), np.asarray(Z.generators)) for Z in d["Zs"]]
+    x0s, e0s = params(d, 4)
+    out = ctl.solve_simplified2_batch(x0s, e0s, N, Zs, d["lp"], d["cp"], ze_sum=ze_sum)
+    assert (out["status"] == 0).all(), out["status"]
+    for b in range(4):
+        o = S2.solve(idn["A"], idn["B"], idn["K"], d["dA"], d["dB"], s["W"], s["X"], s["U"], d["Zs"], N, x0s[b], e0s[b], d["lo"], d["co"],
+                     ze_sum=ze_sum)
+        assert o["status"] == "solved"
+        assert abs(out["cost"][b] - o["result"]) <= 1e-7 * (1 + abs(o["result"]))
+        if name == "di":
+            np.testing.assert_allclose(out["v"][b], o["v"], atol=REL * (1 + np.abs(o["v"]).max()))
+            np.testing.assert_allclose(out["xbar"][b], o["xbar"], atol=REL * (1 + np.abs(o["xbar"]).max()))
+            np.testing.assert_allclose(out["ubar"][b], o["ubar"], atol=REL * (1 + np.abs(o["ubar"]).max()))
+            np.testing.assert_allclose(out["ze1"][b], o["ze1"], atol=REL)
+        else:                                                         # |y - 1| loss: optimal value unique, trajectory not
+            np.testing.assert_allclose(out["xbar"][b, 0], x0s[b], atol=1e-12)
+            np.testing.assert_allclose(out["ze1"][b][:, 1:], o["ze1"][:, 1:], atol=0)
+    res, v, xbar, ze1 = ctl.solve_simplified2(x0s[0], e0s[0], N, Zs, d["lp"], d["cp"], ze_sum=ze_sum)
+    assert abs(res - out["cost"][0]) <= 1e-9 * (1 + abs(res)) and v.shape == (N, d["m"]) and xbar.shape == (N + 1, d["n"])
+    assert ze1.Z.value.shape == out["ze1"][0].shape
+    with pytest.raises(Exception, match="Problem is unbounded"):      # xbar0 + e0 far outside X (reference :496-497)
+        ctl.solve_simplified2(x0s[0] + 100.0, e0s[0], N, Zs, d["lp"], d["cp"], ze_sum=ze_sum)
+
+
+def test_solve_simplified2_segment_state_zonotope_is_infeasible(built):
+    """With the pulley example's one-generator X (examples/2.pulley_sim.py:54) the membership of :422 cannot hold: the reference's
+    solver would return +inf -> 'Problem is unbounded' (:496-497); so does the device path."""
+    from tests.test_oracle_simplified2 import params, problem_data
+    from tzddpc_amd import TZDDPC, Data, SystemZonotopes, Theta, Zonotope
+    d = problem_data("pulley", line_x=True)
+    s, idn, N = d["s"], d["idn"], d["N"]
+    zon = SystemZonotopes(*(Zonotope(np.asarray(s[k].center), np.asarray(s[k].generators)) for k in ("X0", "U", "X", "W")))
+    ctl = TZDDPC(Data(d["u"], d["x"]))
+    ctl.build_zonotopes_theta(zon, theta=Theta(idn["K"], d["dA"], d["dB"]))
+    Zs = [Zonotope(np.asarray(Z.center), np.asarray(Z.generators)) for Z in d["Zs"]]
+    x0s, e0s = params(d, 1)
+    with pytest.raises(Exception, match="Problem is unbounded"):
+        ctl.solve_simplified2(x0s[0], e0s[0], N, Zs, d["lp"], d["cp"])

@@ -87,6 +87,8 @@ class ParametricQP:
     var_names: List[str] = field(default_factory=list)
     # constants for the literal Ze[1] export (reference returns Ze[1], tzddpc.py:377)
     n_v: int = 0
+    # part of the objective constant that is linear in theta beyond xbar0 (solve_simplified2's regulariser only; added on the host)
+    rt: Optional[np.ndarray] = None
 
     def theta_index(self):
         n, m, N = self.n, self.m, self.N
@@ -501,6 +503,185 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
                         tube=tube, row_names=[r[0] for r in qp_rows], var_names=var_names, n_v=N * m)
 
 
+def build_simplified2_qp(Acl, Bhat, K, deltaA, deltaB, W_c, W_G, Zsigma, Xz, Uz, N: int,
+                         build_loss: Callable, build_constraints: Optional[Callable], ze_sum: str = "radius") -> ParametricQP:
+    """The problem of ``TZDDPC.solve_simplified2`` (reference ``tzddpc/tzddpc.py:381-500``) as a two-sided parametric QP in
+    x = [v | beta_u | beta_x | loss epigraphs], theta as in `build_parametric_qp` (only xbar0 and the tube centres C_K^k e0 are
+    used).  xbar and ubar are condensed (``:424-428, :445``: xbar_{k+1} = Acl xbar_k + B v_k, ubar_k = K xbar_k + v_k); the
+    zonotope memberships of ``:421-422`` stay as equality rows in beta (``eliminate_equalities`` removes them before the device
+    sees the problem).  The error tubes have CONSTANT generators here (``:432-436``: W + Zsigma propagated by Acl), their centres
+    are affine in (e0, xbar0, v) through ``term_2`` (``:459``; ``term_2 @ Acl`` on a vector is Acl' term_2).
+    Zsigma: list of N (centre, generators); Xz, Uz: (centre, generators) of zonotopes.X / .U.
+    ze_sum: meaning of the un-vendored ``Ze.sum()`` of ``:451`` -- "radius": row sums of |generators|, "columns": row sums of [c | G]."""
+    Acl = np.asarray(Acl, float); Bhat = np.asarray(Bhat, float); K = np.atleast_2d(np.asarray(K, float))
+    dA = np.asarray(deltaA, float); dB = np.asarray(deltaB, float)
+    n, m = Bhat.shape
+    assert len(Zsigma) == N, "Zsigma needs to be a list of zonotopes of length == N, the horizon"
+    Xc, XG = np.asarray(Xz[0], float), np.asarray(Xz[1], float).reshape(n, -1)
+    Uc, UG = np.asarray(Uz[0], float), np.asarray(Uz[1], float).reshape(m, -1)
+    gx, gu = XG.shape[1], UG.shape[1]
+    nvv = N * m
+    o_bu, o_bx = nvv, nvv + N * gu
+    nzb = o_bx + N * gx
+    # condensed trajectories: xbar_k = Phi_k xbar0 + Gam_k v ; ubar_k = K xbar_k + v_k ; term_2_k = T0_k xbar0 + Tv_k v
+    Phi = np.zeros((N + 1, n, n)); Gam = np.zeros((N + 1, n, nvv)); Phi[0] = np.eye(n)
+    for k in range(N):
+        Phi[k + 1] = Acl @ Phi[k]; Gam[k + 1] = Acl @ Gam[k]; Gam[k + 1][:, k * m:(k + 1) * m] += Bhat
+    Up = np.zeros((N, m, n)); Uv = np.zeros((N, m, nvv))
+    for k in range(N):
+        Up[k] = K @ Phi[k]; Uv[k] = K @ Gam[k]; Uv[k][:, k * m:(k + 1) * m] += np.eye(m)
+    T0 = np.zeros((N + 1, n, n)); Tv = np.zeros((N + 1, n, nvv))
+    for k in range(N):
+        T0[k + 1] = Acl.T @ T0[k] + dA @ Phi[k] + dB @ Up[k]
+        Tv[k + 1] = Acl.T @ Tv[k] + dA @ Gam[k] + dB @ Uv[k]
+    # constant part of the tubes: term_1 (:432-436)
+    Wc, WG = np.asarray(W_c, float).reshape(n), np.asarray(W_G, float).reshape(n, -1)
+    c1 = np.zeros((N, n)); G1 = []
+    for k in range(N):
+        sc, sG = np.asarray(Zsigma[k][0], float).reshape(n), np.asarray(Zsigma[k][1], float).reshape(n, -1)
+        if k == 0:
+            c1[0] = Wc + sc; G1.append(np.concatenate([WG, sG], axis=1))
+        else:
+            c1[k] = Acl @ c1[k - 1] + Wc + sc; G1.append(np.concatenate([Acl @ G1[-1], WG, sG], axis=1))
+    gens = [np.zeros((n, 1))] + [np.concatenate([np.zeros((n, 1)), G1[k]], axis=1) for k in range(N)]     # Ze[0 .. N]
+    cen_c = np.zeros((N + 1, n)); cen_c[1:] = c1
+    # ---- callbacks (:465, :474): loss / constraints on (ubar, xbar[1:]) ---------------------------------------------------
+    nsym = nvv + n
+    sv, sp = slice(0, nvv), slice(nvv, nsym)
+    Cu = np.zeros((nvv, nsym)); Cx = np.zeros(((N + 1) * n, nsym))
+    Cu[:, sv] = Uv.reshape(nvv, nvv); Cu[:, sp] = Up.reshape(nvv, n)
+    Cx[:, sv] = Gam.reshape((N + 1) * n, nvv); Cx[:, sp] = Phi.reshape((N + 1) * n, n)
+    ubar_expr = Affine(Cu, np.zeros(nvv), (N, m)); xbar_expr = Affine(Cx, np.zeros((N + 1) * n), (N + 1, n))
+    loss = build_loss(ubar_expr, xbar_expr[1:])
+    if loss is None:
+        raise Exception("Loss function is not defined or is not convex!")
+    loss = cplite.as_convex(loss, nsym)
+    cons = build_constraints(ubar_expr, xbar_expr[1:]) if build_constraints is not None else []
+    cons = [] if cons is None else list(cons)
+    for idx, c in enumerate(cons):
+        if c is None or not isinstance(c, Constraint):
+            raise Exception(f"Constraint {idx} is not defined or is not convex.")
+    epi_specs = []
+    for w, e in loss.ab:
+        for r in range(e.size):
+            if w != 0.0 and np.any(e.C[r]):
+                epi_specs.append((w, [(e.C[r], e.d[r])]))
+    for w, e in loss.mx:
+        rows_ = [(e.C[r], e.d[r]) for r in range(e.size)]
+        if w != 0.0 and any(np.any(c) for c, _ in rows_):
+            epi_specs.append((w, rows_))
+    s_var0 = nzb
+    nz = nzb + len(epi_specs)
+    var_names = ([f"v[{k},{j}]" for k in range(N) for j in range(m)] + [f"beta_u[{k},{g}]" for k in range(N) for g in range(gu)]
+                 + [f"beta_x[{k},{g}]" for k in range(N) for g in range(gx)] + [f"s[{i}]" for i in range(len(epi_specs))])
+    ntheta = 2 * n + N * (2 * n + m)
+    blk = 2 * n + m
+    ix_c = lambda k, i: 2 * n + k * blk + i
+    rows = []
+    zt = lambda: np.zeros(ntheta)
+
+    def vrow(coef_v):
+        z = np.zeros(nz); z[:nvv] = coef_v
+        return z
+
+    for k in range(N):                                                                                  # :417-420
+        for g in range(gu):
+            z = np.zeros(nz); z[o_bu + k * gu + g] = 1.0; rows.append((f"beta_u[{k},{g}]", z, -1.0, zt(), 1.0, zt()))
+        for g in range(gx):
+            z = np.zeros(nz); z[o_bx + k * gx + g] = 1.0; rows.append((f"beta_x[{k},{g}]", z, -1.0, zt(), 1.0, zt()))
+    for k in range(N):
+        for j in range(m):                                                                              # :421
+            z = vrow(Uv[k][j]); z[o_bu + k * gu:o_bu + (k + 1) * gu] = -UG[j]
+            th = zt(); th[:n] = -Up[k][j]
+            rows.append((f"Umem[{k},{j}]", z, Uc[j], th, Uc[j], th.copy()))
+        for i in range(n):                                                                              # :422
+            z = vrow(Gam[k + 1][i]); z[o_bx + k * gx:o_bx + (k + 1) * gx] = -XG[i]
+            th = zt(); th[:n] = -Phi[k + 1][i]
+            rows.append((f"Xmem[{k + 1},{i}]", z, Xc[i], th, Xc[i], th.copy()))
+    xl, xu = Xc - np.abs(XG).sum(axis=1), Xc + np.abs(XG).sum(axis=1)
+    ul, uu = Uc - np.abs(UG).sum(axis=1), Uc + np.abs(UG).sum(axis=1)
+    for k in range(N):                                                                                  # :440-449
+        radx = np.abs(gens[k]).sum(axis=1); radu = np.abs(K @ gens[k]).sum(axis=1)
+        for i in range(n):
+            z = vrow(Gam[k][i] + Tv[k][i])
+            th = zt(); th[:n] = -(Phi[k][i] + T0[k][i]); th[ix_c(k, i)] -= 1.0
+            rows.append((f"X[{k},{i}]", z, xl[i] - cen_c[k, i] + radx[i], th, xu[i] - cen_c[k, i] - radx[i], th.copy()))
+        for j in range(m):
+            z = vrow(Uv[k][j] + K[j] @ Tv[k])
+            th = zt(); th[:n] = -(Up[k][j] + K[j] @ T0[k])
+            for i in range(n):
+                th[ix_c(k, i)] -= K[j, i]
+            kc = K[j] @ cen_c[k]
+            rows.append((f"U[{k},{j}]", z, ul[j] - kc + radu[j], th, uu[j] - kc - radu[j], th.copy()))
+    # ---- objective ---------------------------------------------------------------------------------------------------------
+    P = np.zeros((nz, nz)); q0 = np.zeros(nz); Qt = np.zeros((nz, ntheta))
+    r0 = float(loss.const); r1 = loss.lin[sp].copy(); R2 = np.zeros((n, n)); rt = np.zeros(ntheta)
+    q0[:nvv] += loss.lin[sv]
+    for w, e in loss.sq:
+        if w == 0.0:
+            continue
+        F = np.zeros((e.size, nz)); F[:, :nvv] = e.C[:, sv]; Gp_ = e.C[:, sp]
+        P += 2.0 * w * F.T @ F; q0 += 2.0 * w * F.T @ e.d; Qt[:, :n] += 2.0 * w * F.T @ Gp_
+        r0 += w * float(e.d @ e.d); r1 += 2.0 * w * Gp_.T @ e.d; R2 += w * Gp_.T @ Gp_
+    for w, e in loss.ab:
+        for r in range(e.size):
+            if not np.any(e.C[r]):
+                r0 += w * abs(float(e.d[r]))
+    for si, (w, rows_) in enumerate(epi_specs):
+        zi = s_var0 + si
+        q0[zi] += w
+        for Crow, d in rows_:
+            zc = vrow(Crow[sv]); e_s = np.zeros(nz); e_s[zi] = 1.0
+            th = zt(); th[:n] = Crow[sp]
+            rows.append((f"s+[{si}]", e_s - zc, d, th, np.inf, zt()))
+            rows.append((f"s-[{si}]", e_s + zc, -d, -th, np.inf, zt()))
+    for k in range(N):                                                                                  # :451 regulariser
+        if ze_sum == "radius":
+            r0 += float(np.abs(gens[k]).sum())
+        elif ze_sum == "columns":
+            r0 += float(cen_c[k].sum() + gens[k].sum())
+            q0[:nvv] += Tv[k].sum(axis=0); r1 += T0[k].sum(axis=0)
+            for i in range(n):
+                rt[ix_c(k, i)] += 1.0
+        else:
+            raise ValueError(f"ze_sum={ze_sum!r}")
+    for ci, c in enumerate(cons):
+        e = c.expr
+        for r in range(e.size):
+            zc = vrow(e.C[r][sv]); th = zt(); th[:n] = -e.C[r][sp]
+            d = -float(e.d[r])
+            if c.kind == "<=":
+                rows.append((f"user[{ci},{r}]", zc, -np.inf, zt(), d, th))
+            elif c.kind == ">=":
+                rows.append((f"user[{ci},{r}]", zc, d, th, np.inf, zt()))
+            else:
+                rows.append((f"user[{ci},{r}]", zc, d, th, d, th.copy()))
+    qp_rows = [r for r in rows if np.any(r[1])]
+    pr_rows = [r for r in rows if not np.any(r[1])]
+    nc = len(qp_rows)
+    A = np.array([r[1] for r in qp_rows]).reshape(nc, nz)
+    l0 = np.array([r[2] for r in qp_rows]); Lt = np.array([r[3] for r in qp_rows]).reshape(nc, ntheta)
+    u0 = np.array([r[4] for r in qp_rows]); Ut = np.array([r[5] for r in qp_rows]).reshape(nc, ntheta)
+    f0, Ftl, pl, pu = [], [], [], []
+    for name, _, lo_c, lo_t, hi_c, hi_t in pr_rows:              # need lo_c + lo_t theta <= 0 <= hi_c + hi_t theta
+        if np.isfinite(lo_c):
+            f0.append(lo_c); Ftl.append(lo_t); pl.append(-np.inf); pu.append(0.0)
+        if np.isfinite(hi_c):
+            f0.append(hi_c); Ftl.append(hi_t); pl.append(0.0); pu.append(np.inf)
+    pmax = max(N - 1, 0)
+    absCK = np.zeros((max(pmax, 1), n, n)); absKCK = np.zeros((max(pmax, 1), m, n))
+    Mp = np.eye(n)
+    for j in range(max(pmax, 1)):
+        absCK[j] = np.abs(Mp); absKCK[j] = np.abs(K @ Mp); Mp = Acl @ Mp
+    tube = TubeConstants(n, m, N, Acl.copy(), np.zeros((n, n)), K.copy(), pmax, absCK, absKCK, np.arange(N, dtype=np.int32))
+    qp = ParametricQP(n=n, m=m, N=N, nz=nz, nc=nc, ntheta=ntheta, P=0.5 * (P + P.T), A=A, q0=q0, Qt=Qt, l0=l0, Lt=Lt, u0=u0, Ut=Ut,
+                      f0=np.array(f0), Ft=np.array(Ftl).reshape(len(f0), ntheta), pl=np.array(pl), pu=np.array(pu),
+                      r0=r0, r1=r1, R2=R2, Phi=Phi.reshape((N + 1) * n, n), Gam=Gam.reshape((N + 1) * n, nvv), tube=tube,
+                      row_names=[r[0] for r in qp_rows], var_names=var_names, n_v=nvv, rt=rt if np.any(rt) else None)
+    qp.s2 = dict(gens=gens, cen_c=cen_c, T0=T0, Tv=Tv, Up=Up, Uv=Uv)        # for Ze[1] / ubar of the returned solution
+    return qp
+
+
 @dataclass
 class Elimination:
     """x = x0 + Xn xbar0 + Z y : the equality rows of the two-sided problem solved for `basic` variables (QR with column
@@ -530,8 +711,9 @@ def eliminate_equalities(qp: ParametricQP):
     d = np.abs(np.diag(R)) if R.size else np.zeros(0)
     rank = int(np.count_nonzero(d > max(E.shape) * np.finfo(float).eps * (d[0] if d.size else 1.0)))
     rhs = Q.T @ np.hstack([f0[:, None], Ft[:, :n]])
-    if rank < E.shape[0] and np.abs(rhs[rank:]).max(initial=0.0) > 1e-9 * (1.0 + np.abs(rhs).max()):
-        raise Exception("Constraint rows from build_constraints are linearly dependent with inconsistent right-hand sides")
+    # dependent equality rows: 0 = rhs_c + rhs_x xbar0 must hold for the problem to be feasible at all -> parameter tests (the
+    # reference's solver would report such a problem infeasible at solve time, :374-375 / :496-497)
+    dep = [i for i in range(rank, E.shape[0]) if np.abs(rhs[i]).max() > 1e-12 * (1.0 + np.abs(rhs).max())]
     basic, free = piv[:rank], np.sort(piv[rank:])
     R1 = R[:rank, :rank]
     col_of = {int(c): i for i, c in enumerate(piv[rank:])}
@@ -565,12 +747,15 @@ def eliminate_equalities(qp: ParametricQP):
             f0p.append([l02[i]]); Ftp.append(Lt2[i][None]); plp.append([-np.inf]); pup.append([0.0])
         if np.isfinite(u02[i]):
             f0p.append([u02[i]]); Ftp.append(Ut2[i][None]); plp.append([0.0]); pup.append([np.inf])
+    for i in dep:
+        row = np.zeros(nth); row[:n] = rhs[i, 1:]
+        f0p.append([rhs[i, 0]]); Ftp.append(row[None]); plp.append([-1e-9]); pup.append([1e-9])
     names = [qp.var_names[i] for i in free] + [f"pad[{i}]" for i in range(npad)]
     red = ParametricQP(n=n, m=qp.m, N=qp.N, nz=ny, nc=int(live.sum()), ntheta=nth, P=0.5 * (P2 + P2.T), A=A2[live],
                        q0=q02, Qt=Qt2, l0=l02[live], Lt=Lt2[live], u0=u02[live], Ut=Ut2[live],
                        f0=np.concatenate(f0p), Ft=np.vstack(Ftp), pl=np.concatenate(plp), pu=np.concatenate(pup),
                        r0=float(r0), r1=r1, R2=R2, Phi=qp.Phi, Gam=qp.Gam, tube=qp.tube,
-                       row_names=[qp.row_names[i] for i in rest[live]], var_names=names, n_v=qp.n_v)
+                       row_names=[qp.row_names[i] for i in rest[live]], var_names=names, n_v=qp.n_v, rt=qp.rt)
     free_idx = np.concatenate([free, -np.ones(npad, dtype=free.dtype)])
     return red, Elimination(x0=x0, Xn=Xn, Z=Z, free=free_idx, eq_rows=np.nonzero(eq)[0], keep_rows=rest[live])
 

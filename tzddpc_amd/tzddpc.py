@@ -116,6 +116,9 @@ class TZDDPC(object):
         if getattr(self, "_gs_full", None) is not None:
             self._gs_full[1].close()
         self._gs_full = None
+        if getattr(self, "_s2", None) is not None:
+            self._s2["native"].close()
+        self._s2 = None
 
     # ---- reference :67-85 ------------------------------------------------------------------------
     def build_zonotopes(self, zonotopes: SystemZonotopes):
@@ -227,11 +230,24 @@ class TZDDPC(object):
         self.qp = qp
         self.horizon = int(horizon)
         self.k0 = k0
+        warm_shift = solver_kwargs.pop("warm_shift", "auto")
+        self._drop_native()
+        self._native, info = self._native_from_qp(qp, solver_kwargs)
+        self._elim, self._scal, self._row_of = info["elim"], info["scal"], info["row_of"]
+        self.warm_shift_policy = self._choose_warm_shift(warm_shift, A, B)
+        self.problem_full = self._native
+        self.optimization_problem = self._native
+        return self._native
+
+    def _native_from_qp(self, qp_full, solver_kwargs):
+        """Two-sided parametric QP -> device problem (``tz_problem_create``): equality elimination, one-sided rows, Ruiz
+        equilibration, warm-start shift maps.  Returns (native.Problem, dict(elim, scal, row_of, qp))."""
+        n, m, horizon = qp_full.n, qp_full.m, qp_full.N
+        qp = qp_full
         # `==` rows of build_constraints (reference :213-219) are eliminated here: the kernel sees inequality rows only and
         # recovers v through an affine map (self.qp stays the two-sided problem with its equality rows)
         from .builder import eliminate_equalities
         qp, elim = eliminate_equalities(qp)
-        self._elim = elim
         rec = {}
         # one-sided, equilibrated form for the interior-point kernel
         fu = np.isfinite(qp.u0); fl = np.isfinite(qp.l0)
@@ -241,16 +257,14 @@ class TZDDPC(object):
         row_of = np.concatenate([np.nonzero(fu)[0], np.nonzero(fl)[0]]).astype(np.int32)
         q_ref = np.abs(qp.q0) + np.abs(qp.Qt).sum(axis=1)
         D, E, c = _ruiz(qp.P, G, q_ref)
-        self._scal = (D, E, c)
         nc_rows = qp.nc
         if elim is not None:
             nv = int(horizon) * m
             rec = dict(rec_c0=elim.x0[:nv], rec_x0=elim.Xn[:nv], rec_y=elim.Z[:nv] * D[None, :])
-            nc_rows = self.qp.nc
+            nc_rows = qp_full.nc
         row_red = row_of                                                  # rows of the (reduced) problem the kernel works on
         if elim is not None:
             row_of = elim.keep_rows[row_of].astype(np.int32)              # ... and of the problem the caller sees (self.qp)
-        self._row_of = row_of
         # receding-horizon shift of the warm start (maps only; whether it is used is decided below)
         from .builder import horizon_shift
         sv, sr2 = horizon_shift(qp)
@@ -259,11 +273,9 @@ class TZDDPC(object):
         side = np.concatenate([np.zeros(int(fu.sum()), int), np.ones(int(fl.sum()), int)])
         sr = np.array([pos.get((int(sr2[row_red[k]]), int(side[k])), k) for k in range(len(row_red))], dtype=np.int32)
         shift = dict(shift_var=sv.astype(np.int32), shift_row=sr, shift_xscale=D[sv] / D, shift_lscale=E[sr] / E)
-        warm_shift = solver_kwargs.pop("warm_shift", "auto")
         opts = dict(max_iter=int(solver_kwargs.pop("max_iter", 40)), tol=float(solver_kwargs.pop("tol", 1e-10)),
                     reg=float(solver_kwargs.pop("reg", 1e-12)), step_frac=float(solver_kwargs.pop("step_frac", 0.99999)))
-        self._drop_native()
-        self._native = native.Problem(
+        nat = native.Problem(
             self.device, n=n, m=m, N=int(horizon),
             P=c * D[:, None] * qp.P * D[None, :], G=E[:, None] * G * D[None, :],
             q0=c * D * qp.q0, Qt=(c * D)[:, None] * qp.Qt, h0=E * h0, Ht=E[:, None] * Ht,
@@ -272,10 +284,7 @@ class TZDDPC(object):
             nc_rows=nc_rows, row_of=row_of, act_scale=c / (E * E), **rec,
             CK=qp.tube.CK, DK=qp.tube.DK, K=qp.tube.K, pmax=qp.tube.pmax,
             absCKpow=qp.tube.absCKpow, absKCKpow=qp.tube.absKCKpow, power=qp.tube.power, **shift, **opts)
-        self.warm_shift_policy = self._choose_warm_shift(warm_shift, A, B)
-        self.problem_full = self._native
-        self.optimization_problem = self._native
-        return self._native
+        return nat, dict(elim=elim, scal=(D, E, c), row_of=row_of, qp=qp)
 
     def _choose_warm_shift(self, mode, A_model, B_model) -> int:
         """Warm-start policy of the closed-loop entry points (``tz_problem_set_warm_shift``): ``"off"`` / 0, ``"on"`` / 1, an
@@ -332,14 +341,69 @@ class TZDDPC(object):
         self.last_status, self.last_iters = st, int(iters[0])
         return float(cost[0]), v[0], xbar[0], self._ze1(np.asarray(xbar0, float).reshape(-1), np.asarray(e0, float).reshape(-1), v[0][0])
 
+    def _simplified2_problem(self, horizon, Zsigma, build_loss, build_constraints, solver_kwargs):
+        """Device problem of ``solve_simplified2`` for (horizon, Zsigma, callbacks); the reference rebuilds its cvxpy problem on
+        every call (``:406-486``), here it is kept until one of them changes."""
+        from .builder import build_simplified2_qp
+        ze_sum = str(solver_kwargs.pop("ze_sum", "radius"))
+        zs = [(np.asarray(Z.center, float), np.asarray(Z.generators, float)) for Z in Zsigma]
+        key = (int(horizon), build_loss, build_constraints, ze_sum, tuple(c.tobytes() + g.tobytes() for c, g in zs),
+               np.asarray(self.theta.K).tobytes(), np.asarray(self.theta.deltaA).tobytes(), np.asarray(self.theta.deltaB).tobytes())
+        cur = getattr(self, "_s2", None)
+        if cur is not None and cur["key"] == key:
+            return cur
+        if cur is not None:
+            cur["native"].close()
+        n = self.dim_x
+        A, B = self.Mdata.center[:, :n], self.Mdata.center[:, n:]                                         # :413
+        zon = self.zonotopes
+        qp = build_simplified2_qp(A + B @ self.theta.K, B, self.theta.K, self.theta.deltaA, self.theta.deltaB,
+                                  zon.W.center, zon.W.generators, zs, (zon.X.center, zon.X.generators),
+                                  (zon.U.center, zon.U.generators), int(horizon), build_loss, build_constraints, ze_sum)
+        nat, info = self._native_from_qp(qp, solver_kwargs)
+        nat.set_warm_shift(0)
+        self._s2 = dict(key=key, native=nat, qp=qp, info=info)
+        return self._s2
+
+    def solve_simplified2_batch(self, xbar0, e0, horizon, Zsigma, build_loss, build_constraints=None, **solver_kwargs):
+        """B instances of ``solve_simplified2`` in one launch sequence: dict(cost, v, xbar, ubar, status, iters, ze1)."""
+        assert build_loss is not None, "Loss function callback cannot be none"
+        n, m, N = self.dim_x, self.dim_u, int(horizon)
+        xbar0 = np.asarray(xbar0, float).reshape(-1, n); e0 = np.asarray(e0, float).reshape(-1, n)
+        assert e0.shape[1] == n, "Invalid size"
+        assert len(Zsigma) == N, "Zsigma needs to be a list of zonotopes of length == N, the horizon"
+        pr = self._simplified2_problem(N, Zsigma, build_loss, build_constraints, dict(solver_kwargs))
+        v, xbar, cost, status, iters, _ = pr["native"].solve_batch(xbar0, e0)
+        qp = pr["qp"]; s2 = qp.s2
+        if qp.rt is not None:                                    # part of the regulariser that is linear in C_K^k e0
+            from .builder import theta_reference
+            cost = cost + np.array([qp.rt @ theta_reference(qp, xbar0[b], e0[b]) for b in range(xbar0.shape[0])])
+        vf = v.reshape(-1, N * m)
+        ubar = np.einsum("kjc,bc->bkj", s2["Up"], xbar0) + np.einsum("kjc,bc->bkj", s2["Uv"], vf)
+        # Ze[1] (:499): centre Acl e0 + c(term_1[0]) + term_2_1, generators [0 | W | Zsigma[0]]
+        Acl = qp.tube.CK
+        cen = e0 @ Acl.T + s2["cen_c"][1][None] + xbar0 @ s2["T0"][1].T + vf @ s2["Tv"][1].T
+        ze1 = np.concatenate([cen[:, :, None], np.broadcast_to(s2["gens"][1][None], (xbar0.shape[0],) + s2["gens"][1].shape)], axis=2)
+        return dict(cost=cost, v=v, xbar=xbar, ubar=ubar, status=status, iters=iters, ze1=ze1)
+
     def solve_simplified2(self, xbar0, e0, horizon, Zsigma, build_loss, build_constraints=None, **solver_kwargs):
-        """Reference ``tzddpc/tzddpc.py:381-500``: a one-shot alternative formulation (user-supplied ``Zsigma``, numeric
-        ``theta.deltaA / deltaB``, a ``Ze.sum()`` regulariser) that no example of the reference calls.  It is not on the hot path
-        this package re-implements and has no device kernel; stated loudly instead of approximated."""
-        raise NotImplementedError(
-            "solve_simplified2 (reference tzddpc/tzddpc.py:381-500) is not implemented on the MI355X path: it is unused by the "
-            "reference's examples and relies on un-pinned pyzonotope semantics (CVXZonotope.sum); use build_problem / "
-            "build_problem_simplified + solve")
+        """Reference ``tzddpc/tzddpc.py:381-500``: tubes with constant generators (W + the user's ``Zsigma`` propagated by
+        A + B K), centres shifted by the adversarial model errors ``theta.deltaA / deltaB`` (``:459``), nominal states and inputs
+        confined to the zonotopes X and U themselves (``:421-422``), loss and constraints on ``(ubar, xbar[1:])``, a ``Ze.sum()``
+        regulariser (``:451``; un-vendored, see ``ze_sum=`` in ``builder.build_simplified2_qp``).
+        Returns ``(result, v, xbar, Ze[1])`` like the reference (``:499``); same exceptions as ``solve``."""
+        out = self.solve_simplified2_batch(np.asarray(xbar0, float).reshape(1, -1), np.asarray(e0, float).reshape(1, -1),
+                                           horizon, Zsigma, build_loss, build_constraints, **solver_kwargs)
+        st = int(out["status"][0])
+        if st in (native.TZ_MAX_ITER, native.TZ_NUMERICAL):
+            msg = ("Error while solving the simplified TZDDPC problem. Details: the interior-point kernel "
+                   + ("hit its iteration limit" if st == native.TZ_MAX_ITER else "failed numerically"))
+            with open("tzddpc.txt", "w") as f:                                              # :491-493
+                print(msg, file=f)
+            raise Exception(msg)
+        if st != native.TZ_SOLVED or not np.isfinite(out["cost"][0]):
+            raise Exception("Problem is unbounded")                                          # :496-497
+        return float(out["cost"][0]), out["v"][0], out["xbar"][0], TubeZonotope(out["ze1"][0])
 
     def _ze1(self, xbar0, e0, v0) -> TubeZonotope:
         """Literal ``Ze[1] = MdataK * <e0,[0]> + (Mdelta * <[xbar0; v0],[0]> + W)`` (``:172-176, :205``), columns in the
