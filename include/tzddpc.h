@@ -258,6 +258,13 @@ int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, dou
  * integrator N=20: 1; pulley: 0) -- the Python layer calibrates it on a short simulated closed loop at build time. */
 int tz_problem_set_warm_shift(tz_problem* p, int32_t policy);
 
+/* Warm-started steps re-derive the slacks for the new right-hand side and push slacks and multipliers into the cone by
+ *     sigma = max(floor, gain * (largest violation of the new rows by the previous solution))      (scaled units).
+ * The gain that costs the fewest interior-point iterations depends on the problem (measured on MI355X: the 5-dim example needs
+ * 6.4 factorisations per step at gain 1 and 4.0 at 0.003, the pulley is best near 1, the double integrators do not care) -- the
+ * Python layer calibrates it together with the shift policy.  Defaults: floor 1e-8, gain 1. */
+int tz_problem_set_warm_push(tz_problem* p, double floor, double gain);
+
 /* The closed-loop entry points (tz_mpc_step, tz_mpc_run) warm-start every trajectory from the solution the HANDLE holds for it from
  * the previous call with the same batch size.  Call this when the next call starts a new batch of trajectories (fresh x / xbar / e):
  * the next step then starts cold, and results and iteration counts no longer depend on what the handle solved before.

@@ -158,4 +158,5 @@ def c_oracle_for(ctl, **kw):
     from oracle.c_oracle import COracle
     from tzddpc_amd.builder import horizon_shift
     pol = kw.pop("shift_policy", ctl.warm_shift_policy)
+    kw.setdefault("warm_gain", float(getattr(ctl, "warm_push_gain", 1.0)))
     return COracle(ctl.qp, shift_policy=pol, shift_maps=horizon_shift(ctl.qp) if pol else None, **kw)

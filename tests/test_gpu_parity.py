@@ -279,6 +279,7 @@ def test_single_wave_factor_path_equals_four_wave_path(built, monkeypatch):
         for k in ("TZ_CHOL1", "TZ_KSPLIT"):
             monkeypatch.delenv(k, raising=False)
         slow._native.set_warm_shift(fast.warm_shift_policy)      # same policy on both sides (the calibration is per build)
+        slow._native.set_warm_push(1e-8, fast.warm_push_gain)
         noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
         x0 = np.tile(zon.X0.center, (Bn, 1))
         a = fast.simulate_batch(x0, noise, A, B); b = slow.simulate_batch(x0, noise, A, B)
@@ -794,3 +795,28 @@ def test_solve_simplified2_segment_state_zonotope_is_infeasible(built):
     x0s, e0s = params(d, 1)
     with pytest.raises(Exception, match="Problem is unbounded"):
         ctl.solve_simplified2(x0s[0], e0s[0], N, Zs, d["lp"], d["cp"])
+
+
+def test_warm_push_calibration_keeps_parity(built):
+    """The build-time calibration of the warm-start push (tz_problem_set_warm_push) only changes how many iterations a step needs:
+    the 5-dim closed loop is within the north-star tolerance of the C oracle for every candidate gain, and the calibrated gain
+    needs no more factorisations than the default."""
+    from tzddpc_amd.dist import vertex_noise
+    ctl, (A, B, zon) = common.gpu_controller("dim5_n20")
+    assert ctl.warm_push_gain in (1.0, 0.1, 0.01, 0.003)
+    Bn, T = 32, 16
+    noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
+    x0 = np.tile(zon.X0.center, (Bn, 1))
+    ref = common.c_oracle_for(ctl, warm_gain=1.0).simulate_batch(x0, noise, A, B, threads=16)
+    work = {}
+    for g in (1.0, ctl.warm_push_gain, 0.003):
+        ctl._native.set_warm_push(1e-8, g)
+        ctl._native.timing_enable(True)
+        run = ctl.simulate_batch(x0, noise, A, B)
+        work[g] = ctl._native.work_get()["factorizations"]
+        ctl._native.timing_enable(False)
+        assert (run["status"] == 0).all()
+        np.testing.assert_allclose(run["x"], ref["x"], atol=REL * (1 + np.abs(ref["x"]).max()))
+        np.testing.assert_allclose(run["u"], ref["u"], atol=REL * (1 + np.abs(ref["u"]).max()))
+    ctl._native.set_warm_push(1e-8, ctl.warm_push_gain)
+    assert work[ctl.warm_push_gain] <= work[1.0]

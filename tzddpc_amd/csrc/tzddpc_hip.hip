@@ -1107,6 +1107,13 @@ int tz_problem_set_warm_shift(tz_problem* p, int32_t policy) {
   return TZ_OK;
 }
 
+int tz_problem_set_warm_push(tz_problem* p, double floor, double gain) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  if (!(floor > 0.0) || !(gain >= 0.0)) TZ_FAIL(TZ_ERR_INVALID, "floor must be positive, gain non-negative");
+  p->warm_floor = floor; p->warm_gain = gain;
+  return TZ_OK;
+}
+
 int tz_problem_reset_warm(tz_problem* p) {
   if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
   p->have_prev = false;

@@ -104,6 +104,8 @@ def lib():
     for nm in ("tz_genstack_create", "tz_genstack_destroy", "tz_genstack_intervals", "tz_genstack_values", "tz_genstack_info"):
         getattr(L, nm).restype = C.c_int
     L.tz_problem_reset_warm.argtypes = [vp]
+    L.tz_problem_set_warm_push.argtypes = [vp, C.c_double, C.c_double]
+    L.tz_problem_set_warm_push.restype = C.c_int
     L.tz_problem_set_warm_shift.argtypes = [vp, C.c_int32]
     L.tz_timing_enable.argtypes = [vp, C.c_int]
     L.tz_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -123,7 +125,7 @@ def lib():
 EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy",
                     "tz_problem_set_stream", "tz_problem_sync", "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run",
                     "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch",
-                    "tz_problem_set_warm_shift", "tz_problem_reset_warm", "tz_identify_batch", "tz_specrad_batch", "tz_adversary_batch",
+                    "tz_problem_set_warm_shift", "tz_problem_set_warm_push", "tz_problem_reset_warm", "tz_identify_batch", "tz_specrad_batch", "tz_adversary_batch",
                     "tz_genstack_create", "tz_genstack_destroy", "tz_genstack_intervals", "tz_genstack_values", "tz_genstack_info")
 
 
@@ -329,6 +331,9 @@ class Problem:
     def reset_warm(self):
         """The next closed-loop call starts a new batch of trajectories: no warm start from what the handle solved before."""
         check(lib().tz_problem_reset_warm(self._h), "tz_problem_reset_warm")
+
+    def set_warm_push(self, floor: float = 1e-8, gain: float = 1.0):
+        check(lib().tz_problem_set_warm_push(self._h, float(floor), float(gain)), "tz_problem_set_warm_push")
 
     def set_warm_shift(self, policy: int):
         check(lib().tz_problem_set_warm_shift(self._h, int(policy)), "tz_problem_set_warm_shift")

@@ -231,10 +231,12 @@ class TZDDPC(object):
         self.horizon = int(horizon)
         self.k0 = k0
         warm_shift = solver_kwargs.pop("warm_shift", "auto")
+        warm_gain = solver_kwargs.pop("warm_gain", "auto")
         self._drop_native()
         self._native, info = self._native_from_qp(qp, solver_kwargs)
         self._elim, self._scal, self._row_of = info["elim"], info["scal"], info["row_of"]
         self.warm_shift_policy = self._choose_warm_shift(warm_shift, A, B)
+        self.warm_push_gain = self._choose_warm_push(warm_gain, A, B)
         self.problem_full = self._native
         self.optimization_problem = self._native
         return self._native
@@ -319,6 +321,32 @@ class TZDDPC(object):
             raise ValueError(f"warm_shift={mode!r}")
         nat.set_warm_shift(policy)
         return policy
+
+    def _choose_warm_push(self, mode, A_model, B_model) -> float:
+        """Gain of the push that re-centres a warm start (``tz_problem_set_warm_push``): a number, or ``"auto"`` -- the same short
+        simulated closed loop as for the shift policy is run for a few gains and the one with the fewest factorisations is kept if
+        it wins by 3 % (5-dim example: 6.4 -> 4.0 factorisations per step at 0.003; double integrators: no difference -> 1)."""
+        nat = self._native
+        if mode != "auto":
+            gain = float(mode)
+        else:
+            zon = self.zonotopes
+            Wv = zon.W.compute_vertices()
+            Bn, T = 24, 48
+            rng = np.random.default_rng(12345)
+            noise = Wv[rng.integers(0, Wv.shape[0], size=(Bn, T))]
+            x0 = np.tile(np.asarray(zon.X0.center, float), (Bn, 1))
+            best, gain = None, 1.0
+            for cand in (1.0, 0.1, 0.01, 0.003):
+                nat.set_warm_push(1e-8, cand)
+                nat.timing_enable(True)
+                _, _, _, status = nat.simulate_batch(x0, noise, A_model, B_model)
+                work = nat.work_get()["factorizations"] + (10 ** 9 if np.any(status != 0) else 0)
+                nat.timing_enable(False)
+                if best is None or work < 0.97 * best:
+                    best, gain = work, cand
+        nat.set_warm_push(1e-8, gain)
+        return gain
 
     # ---- reference :357-377 ----------------------------------------------------------------------
     def solve(self, xbar0: np.ndarray, e0: np.ndarray, **solver_kwargs) -> Tuple[float, np.ndarray, np.ndarray, TubeZonotope]:
