@@ -196,6 +196,14 @@ int tz_genstack_destroy(tz_genstack* g);
  * time of the streaming kernel of this call */
 int tz_genstack_intervals(tz_genstack* g, int32_t B, const double* e0, const double* zeta,
                           double* centre, double* rad_x, double* rad_u, double* kernel_ms, int mem);
+/* Literal problems (matrix zonotopes with dense generators: one epigraph variable per decision-dependent generator entry, built by
+ * tzddpc_amd/builder.py with literal=...): the decision-INDEPENDENT generators of every tube (constants and M_K^p <e0, 0>, reference
+ * tzddpc/tzddpc.py:175, :181) stay numeric; theta's tube block (centre, rho^x, rho^u per step) is then the interval hull of that
+ * sub-stack, evaluated per solve by the K1g kernels on the problem's stream instead of the collapsed recursion.  The stack is not
+ * owned (destroy it after the problem); closed-loop entry points of such a problem run the four-kernel step (no fused launch).
+ * NULL detaches. */
+int tz_problem_attach_tube_stack(tz_problem* p, tz_genstack* stack);
+
 /* Z : B x n x (1 + Gamma_seg), column 0 the centre, then the generators of Ze[seg] in the reference's order */
 int tz_genstack_values(tz_genstack* g, int32_t seg, int32_t B, const double* e0, const double* zeta, double* Z, int mem);
 /* generators, bytes of the stack streamed per tile of 256 trajectories, chunks (= workgroups per tile) */

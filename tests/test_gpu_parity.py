@@ -547,8 +547,8 @@ def test_literal_tubes_dense_generators_and_collapsed_where_exact(built):
     assert np.count_nonzero(dK.generators.reshape(dK.num_generators, -1), axis=1).max() > 1
     boxedK, boxedD = ctl.MdataK, ctl.Mdelta
     ctl.MdataK, ctl.Mdelta = MatrixZonotope(dK.center, dK.generators), MatrixZonotope(dD.center, dD.generators)
-    with pytest.raises(StructureError):
-        ctl.build_problem(3, common.loss_di, common.nocons)
+    with pytest.raises(StructureError, match="literal problem"):       # horizon 6, full problem: ~1e5 decision-dependent generator entries
+        ctl.build_problem(6, common.loss_di, common.nocons)
     N = 3
     ctl.horizon, ctl.k0 = N, None; ctl._gs_full = None
     Bn = 4
@@ -820,3 +820,65 @@ def test_warm_push_calibration_keeps_parity(built):
         np.testing.assert_allclose(run["u"], ref["u"], atol=REL * (1 + np.abs(ref["u"]).max()))
     ctl._native.set_warm_push(1e-8, ctl.warm_push_gain)
     assert work[ctl.warm_push_gain] <= work[1.0]
+
+
+@pytest.mark.parametrize("N,k0", [(3, None), (4, 1), (2, None)])
+def test_dense_generator_problems_solve_against_oracle_literal(built, N, k0):
+    """Matrix zonotopes with DENSE generators (Girard order 2 of the raw identification instead of the boxes of reduce(1)): no
+    collapse exists; the product builds the literal problem (one epigraph variable per decision-dependent generator entry), the
+    device takes the e0-only part of every tube from the K1g evaluation of the stack (tz_problem_attach_tube_stack) and solves it.
+    Against oracle/literal.py (the reference's generator stacking, reference tzddpc/tzddpc.py:172-207 / :283-324) + the oracle's
+    interior point: cost, consumed input and state; and the closed loop (four-kernel steps) against a host loop of oracle solves."""
+    from oracle import harness as H, literal as L
+    from oracle.qp_ipm import solve_qp
+    from tzddpc_amd import TZDDPC, Data, Theta
+    from tzddpc_amd.harness import system
+    from tzddpc_amd.zonotope import MatrixZonotope
+    s, u, x, idn, rng = _oracle_setup("di_cc")
+    A, B, zon, T = system("di_cc")
+    n, m = B.shape
+    ctl = TZDDPC(Data(u, x))
+    ctl.build_zonotopes_theta(zon, theta=Theta(idn["K"], np.zeros_like(A), np.zeros_like(B)))
+    dK, dD = idn["MdataK_raw"].reduce(2), idn["Mdelta_raw"].reduce(2)
+    ctl.MdataK, ctl.Mdelta = MatrixZonotope(dK.center, dK.generators), MatrixZonotope(dD.center, dD.generators)
+    if k0 is None:
+        ctl.build_problem(N, common.loss_di, common.nocons)
+    else:
+        ctl.build_problem_simplified(k0, N, common.loss_di, common.nocons)
+    assert ctl.qp.nz > N * m + 10 and ctl._gs_tube is not None
+    oloss = H.loss_di
+
+    def oracle(x0, e0):
+        lp = L.build_literal(idn["A"], idn["B"], dK, dD, idn["K"], s["W"], s["X"], s["U"], N, e0, x0, oloss, None, k0)
+        q = L.to_qp(lp)
+        r = solve_qp(q["P"], q["q"], q["A"], q["l"], q["u"], tol=1e-12)
+        assert r.status == "solved"
+        xi = r.x[:lp.nxi]
+        return r.obj + q["r"], xi[(N + 1) * n:].reshape(N, m), xi[:(N + 1) * n].reshape(N + 1, n)
+    Bn = 5
+    x0 = np.tile(zon.X0.center, (Bn, 1)) + 0.05 * rng.standard_normal((Bn, n)); e0 = 0.02 * rng.standard_normal((Bn, n)); e0[0] = 0.0
+    out = ctl.solve_batch(x0, e0)
+    assert (out["status"] == 0).all(), out["status"]
+    for b in range(Bn):
+        cost, v, xb = oracle(x0[b], e0[b])
+        assert abs(out["cost"][b] - cost) <= 1e-7 * (1 + abs(cost))
+        np.testing.assert_allclose(out["v"][b, 0], v[0], atol=REL * (1 + np.abs(v).max()))
+        np.testing.assert_allclose(out["xbar"][b, 1], xb[1], atol=REL * (1 + np.abs(xb).max()))
+    res, v1, xb1, ze1 = ctl.solve(x0[1], e0[1])
+    assert abs(res - out["cost"][1]) <= 1e-9 * (1 + abs(res))
+    # closed loop: three steps of two trajectories
+    Wv = zon.W.compute_vertices()
+    noise = Wv[np.random.default_rng(9).integers(0, Wv.shape[0], size=(2, 3))]
+    xs = np.tile(zon.X0.center, (2, 1))
+    sim = ctl.simulate_batch(xs, noise, A, B)
+    assert (sim["status"] == 0).all()
+    K = ctl.theta.K
+    for b in range(2):
+        xx = xs[b].copy(); xbar = xx.copy(); e = np.zeros(n)
+        for t in range(3):
+            _, v, xb = oracle(xbar, e)
+            uu = v[0] + K @ e
+            np.testing.assert_allclose(sim["u"][b, t], uu, atol=REL * (1 + np.abs(uu).max()))
+            xx = A @ xx + B @ uu + noise[b, t]
+            xbar = xb[1]; e = xx - xbar
+            np.testing.assert_allclose(sim["x"][b, t + 1], xx, atol=REL * (1 + np.abs(xx).max()))

@@ -78,9 +78,9 @@ def test_structure_error_for_dense_generators():
     ctl = TZDDPC.__new__(TZDDPC); ctl.device = 0; ctl._native = None; ctl.qp = None
     ctl.update_identification_data(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, np.random.default_rng(3)))
     ctl.build_zonotopes_theta(zon)
-    ctl.MdataK.generators[0][0, 1] = 0.3                        # a generator with two non-zeros: literal path needed
-    with pytest.raises(StructureError):
-        ctl.build_problem(3, common.loss_di, common.nocons)
+    ctl.MdataK.generators[0][0, 1] = 0.3                        # a generator with two non-zeros: no collapse, the literal problem
+    with pytest.raises(StructureError, match="literal problem"):   # ... which outgrows the device solver at this horizon
+        ctl.build_problem(12, common.loss_di, common.nocons)
 
 
 def test_header_symbols_are_exported(built):

@@ -78,3 +78,40 @@ def test_product_builder_matches_oracle_collapsed(case):
         v, xb = C.extract(cq, r.x)
         np.testing.assert_allclose(ref["v"][0], v[0], atol=2e-6)
         np.testing.assert_allclose(ref["xbar"][1], xb[1], atol=2e-6)
+
+
+@pytest.mark.parametrize("N,k0", [(3, None), (4, 1), (2, None)])
+def test_product_literal_problem_matches_oracle_literal_for_dense_generators(N, k0):
+    """Dense matrix-zonotope generators (Girard order 2): the product's literal problem (`build_parametric_qp(..., literal=stack)`,
+    epigraph variables only for the decision-dependent generator entries, the rest numeric through theta) has the optimum of the
+    oracle's literal restatement (every generator entry an epigraph, reference tzddpc/tzddpc.py:172-207 / :283-324)."""
+    from oracle import harness as H, literal as OL
+    from oracle.qp_ipm import solve_qp
+    from tests import common
+    from tzddpc_amd.builder import build_parametric_qp, theta_reference
+    from tzddpc_amd.genstack import build_stack, count_generators
+    from tzddpc_amd.zonotope import MatrixZonotope as PMZ, Zonotope as PZ
+    s = H.system("di_cc"); rng = np.random.default_rng(25)
+    u, x = H.generate_trajectories(s["A"], s["B"], s["X0"], s["U"], s["W"], 1, s["T"], rng)
+    idn = H.identify(u, x, s["W"])
+    dK, dD = idn["MdataK_raw"].reduce(2), idn["Mdelta_raw"].reduce(2)
+    n, m = 2, 1
+    pK, pD = PMZ(np.asarray(dK.center), np.asarray(dK.generators)), PMZ(np.asarray(dD.center), np.asarray(dD.generators))
+    W = PZ(np.asarray(s["W"].center), np.asarray(s["W"].generators))
+    st = build_stack(pK, pD, idn["K"], W, n, m, N, k0, nseg=N)
+    tot, dec = count_generators(pK.num_generators, pD.num_generators, W.num_generators, N, k0, nseg=N)
+    assert list(np.diff(st.seg_ptr)) == tot
+    Xi, Ui = s["X"].interval, s["U"].interval
+    qp = build_parametric_qp(idn["A"], idn["B"], np.asarray(dK.center), None, None, idn["K"], W.center, W.generators,
+                             Xi.left_limit, Xi.right_limit, Ui.left_limit, Ui.right_limit, N, common.loss_di, common.nocons, k0, literal=st)
+    assert qp.nz <= N * m + sum(dec) * (n + m) + 2 * N
+    for b in range(3):
+        x0 = np.asarray(s["X0"].center) + 0.05 * rng.standard_normal(2); e0 = 0.02 * rng.standard_normal(2)
+        th = theta_reference(qp, x0, e0)
+        r = solve_qp(qp.P, qp.q0 + qp.Qt @ th, qp.A, qp.l0 + qp.Lt @ th, qp.u0 + qp.Ut @ th, tol=1e-12)
+        cost = r.obj + qp.r0 + qp.r1 @ x0 + x0 @ qp.R2 @ x0
+        q = OL.to_qp(OL.build_literal(idn["A"], idn["B"], dK, dD, idn["K"], s["W"], s["X"], s["U"], N, e0, x0, H.loss_di, None, k0))
+        ro = solve_qp(q["P"], q["q"], q["A"], q["l"], q["u"], tol=1e-12)
+        assert r.status == "solved" == ro.status
+        assert abs(cost - (ro.obj + q["r"])) <= 1e-7 * (1 + abs(cost))
+        np.testing.assert_allclose(r.x[:m], ro.x[(N + 1) * n:(N + 1) * n + m], atol=1e-6)

@@ -184,7 +184,7 @@ def newton_cost(qp: "ParametricQP") -> float:
 
 def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: int,
                         build_loss: Callable, build_constraints: Optional[Callable],
-                        k0: Optional[int] = None, epigraph: str = "auto") -> ParametricQP:
+                        k0: Optional[int] = None, epigraph: str = "auto", literal=None) -> ParametricQP:
     """epigraph: "component" -- one variable t_{j,c} >= |zeta_{j,c}| per used component (2 rows each);
                  "aggregate" -- when Delta^delta is rank one (rho s'), every radius depends on t_j only through
                                 tau_j = s'|zeta_j|: one variable per step j and 2^(#components) sign rows
@@ -193,7 +193,13 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
                                 tau_{j,G} >= sum_{c in G} (+-) s_c zeta_{j,c}: ceil(p / g) variables and at most 2^g rows per
                                 group and step (g = p is "aggregate", g = 1 the component form written in tau);
                  "auto"      -- rank one: the group size with the cheapest Newton system (`newton_cost` of the assembled
-                                candidates), else "component"."""
+                                candidates), else "component".
+    literal: a `genstack.GenStack` of the tubes Ze[0..N-1] -- the LITERAL problem for matrix zonotopes with dense generators
+             (no collapse possible): one epigraph variable per entry of every generator column that depends on a decision
+             variable, `t >= |m0_i + M_i zeta_j|` (what cvxpy's canonicalisation of ``.interval`` does, reference ``:191-197``);
+             the generators that depend on e0 only stay numeric: their radii reach the problem through theta's rho entries,
+             which the device then takes from the stack (``tz_problem_attach_tube_stack``), not from the collapsed recursion.
+             DK / Dd are ignored.  Sized by the caller: N * (generators per tube) * (n + m) variables."""
     Ahat = np.asarray(Ahat, float); Bhat = np.asarray(Bhat, float)
     K = np.atleast_2d(np.asarray(K, float))
     n, m = Bhat.shape
@@ -209,6 +215,8 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
         Gam[k + 1] = Ahat @ Gam[k]
         Gam[k + 1][:, k * m:(k + 1) * m] += Bhat
 
+    if literal is not None:
+        DK = np.zeros((n, n)); Dd = np.zeros((n, p)); epigraph = "component"
     # ---- noise chains term2[k'] (e0-independent; numeric centers, boxes affine in t) -----------
     Z_noise = []
     for j in range(N):                                                   # ``:176``
@@ -237,6 +245,28 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
         rx0[k], rxT[k] = Zn.radius(np.eye(n), nt)
         ru0[k], ruT[k] = Zn.radius(K, nt)
 
+    lit_x, lit_u = [], []             # literal mode: (tube k, row i, generator g) of every decision-dependent entry
+    if literal is not None:
+        st = literal
+        assert st.nseg >= N and st.n == n and st.m == m
+        cn[:] = st.c0[:N]; rx0[:] = 0.0; ru0[:] = 0.0; rxT[:] = 0.0; ruT[:] = 0.0
+        Mp_ = np.eye(n)
+        pw_mats = [Mp_]
+        for _ in range(pmax):
+            pw_mats.append(CK @ pw_mats[-1])
+        for k in range(N):
+            assert np.allclose(st.cE[k], pw_mats[int(power[k])], atol=1e-12), "centre chain of the stack is not C_K^power"
+            assert not np.any(st.cZ[k]), "tube centres that depend on the decision variables are not expected (Mdelta has a zero centre)"
+            for g in range(int(st.seg_ptr[k]), int(st.seg_ptr[k + 1])):
+                if st.src[g] <= 0:
+                    continue                                  # constant or e0-sourced: numeric per solve (theta)
+                for i in range(n):
+                    if np.any(st.M[g, i]):
+                        lit_x.append((k, i, g))
+                KM = K @ st.M[g]
+                for j2 in range(m):
+                    if np.any(KM[j2]):
+                        lit_u.append((k, j2, g))
     # ---- which |.| epigraphs are needed --------------------------------------------------------
     used = (np.abs(rxT).sum(axis=(0, 1)) + np.abs(ruT).sum(axis=(0, 1))) > 0      # (nt,)
     t_var = {}                       # (j, c) -> z index            (component form)
@@ -281,6 +311,12 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
                     t_var[(j, c)] = nzc; nzc += 1
                     var_names.append(f"t[{j},{c}]")
 
+    lit_x0 = nzc
+    nzc += len(lit_x)
+    var_names += [f"lx[{k},{i},{g}]" for k, i, g in lit_x]
+    lit_u0 = nzc
+    nzc += len(lit_u)
+    var_names += [f"lu[{k},{j},{g}]" for k, j, g in lit_u]
     # ---- callbacks on look-alike variables -----------------------------------------------------
     nsym = N * m + N * m + n                       # [v | u_free | xbar0]
     sv = slice(0, N * m); su = slice(N * m, 2 * N * m); sp = slice(2 * N * m, nsym)
@@ -384,6 +420,9 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
                     tt[zi] = rxT[k][i, j * p + c]
                 for c in range(n):
                     th_abs[ix_ax0(c)] = rxT[k][i, c]             # j = 0, xbar part -> |xbar0|
+            for q_, (k2, i2, _) in enumerate(lit_x):
+                if k2 == k and i2 == i:
+                    tt[lit_x0 + q_] = 1.0
             base = zeros_t()
             base[[ix_x0(c) for c in range(n)]] = Phi[k][i]
             base[ix_c(k, i)] += 1.0
@@ -405,6 +444,9 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
                     tt[zi] = ruT[k][j2, j * p + c]
                 for c in range(n):
                     th_abs[ix_ax0(c)] = ruT[k][j2, c]
+            for q_, (k2, j3, _) in enumerate(lit_u):
+                if k2 == k and j3 == j2:
+                    tt[lit_u0 + q_] = 1.0
             base = zeros_t()
             for i in range(n):
                 base[ix_c(k, i)] += K[j2, i]
@@ -431,6 +473,18 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
                         for c in par_c:
                             th[ix_ax0(c)] += s_w[c]
                     add_row(f"{vname}{''.join('+' if sg > 0 else '-' for sg in signs)}", zrow, 0.0, th, np.inf, zeros_t())
+    # ---- literal epigraphs: t >= |L (m0 + M zeta_j)| row by row, zeta_j = [Phi_j xbar0 + Gam_j v ; v_j] -------------------------
+    for base_, entries, left in ((lit_x0, lit_x, None), (lit_u0, lit_u, K)):
+        for q_, (k, i, g) in enumerate(entries):
+            j = int(literal.src[g]) - 1
+            rowM = literal.M[g][i] if left is None else left[i] @ literal.M[g]
+            c_ = float(literal.m0[g][i] if left is None else left[i] @ literal.m0[g])
+            f = np.zeros(nz); f[:N * m] = rowM[:n] @ Gam[j]; f[j * m:(j + 1) * m] += rowM[n:]
+            th = zeros_t(); th[[ix_x0(cc) for cc in range(n)]] = rowM[:n] @ Phi[j]
+            e_t = np.zeros(nz); e_t[base_ + q_] = 1.0
+            nm = var_names[base_ + q_]
+            add_row(f"{nm}+", e_t - f, c_, th, np.inf, zeros_t())           # t - f(v) >= c + th.theta
+            add_row(f"{nm}-", e_t + f, -c_, -th, np.inf, zeros_t())
     # ---- t >= |zeta| (component form) ----------------------------------------------------------
     for (j, c), zi in t_var.items():
         zeta = np.zeros(nz); zt = zeros_t()
@@ -497,10 +551,14 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
     keep = np.isfinite(pl) | np.isfinite(pu)
     Ft, f0, pl, pu = Ft[keep], f0[keep], pl[keep], pu[keep]
 
-    return ParametricQP(n=n, m=m, N=N, nz=nz, nc=nc, ntheta=ntheta, P=0.5 * (P + P.T), A=A,
-                        q0=q0, Qt=Qt, l0=l0, Lt=Lt, u0=u0, Ut=Ut, f0=f0, Ft=Ft, pl=pl, pu=pu,
-                        r0=r0, r1=r1, R2=R2, Phi=Phi.reshape((N + 1) * n, n), Gam=Gam.reshape((N + 1) * n, N * m),
-                        tube=tube, row_names=[r[0] for r in qp_rows], var_names=var_names, n_v=N * m)
+    out = ParametricQP(n=n, m=m, N=N, nz=nz, nc=nc, ntheta=ntheta, P=0.5 * (P + P.T), A=A,
+                       q0=q0, Qt=Qt, l0=l0, Lt=Lt, u0=u0, Ut=Ut, f0=f0, Ft=Ft, pl=pl, pu=pu,
+                       r0=r0, r1=r1, R2=R2, Phi=Phi.reshape((N + 1) * n, n), Gam=Gam.reshape((N + 1) * n, N * m),
+                       tube=tube, row_names=[r[0] for r in qp_rows], var_names=var_names, n_v=N * m)
+    if literal is not None:
+        from .genstack import restrict_to_e0
+        out.estack = restrict_to_e0(literal, N)
+    return out
 
 
 def build_simplified2_qp(Acl, Bhat, K, deltaA, deltaB, W_c, W_G, Zsigma, Xz, Uz, N: int,
@@ -806,4 +864,10 @@ def tube_reference(tube: TubeConstants, e0: np.ndarray):
 
 
 def theta_reference(qp: ParametricQP, xbar0, e0):
-    return np.concatenate([np.asarray(xbar0, float), np.abs(np.asarray(xbar0, float)), tube_reference(qp.tube, e0)])
+    if getattr(qp, "estack", None) is not None:              # literal problem: the e0-only generators evaluated one by one
+        from .genstack import evaluate_host
+        st = qp.estack
+        tb = np.concatenate([np.concatenate(t) for t in evaluate_host(st, np.asarray(e0, float), np.zeros((st.N, st.n + st.m)))[:qp.N]])
+    else:
+        tb = tube_reference(qp.tube, e0)
+    return np.concatenate([np.asarray(xbar0, float), np.abs(np.asarray(xbar0, float)), tb])

@@ -175,3 +175,23 @@ __global__ void tz_genstack_values_kernel(GsValuesParams q) {
     out[(size_t)i * cols] = a;
   }
 }
+
+// Literal problems (dense generators): theta's tube block (c_k, rho^x_k, rho^u_k)_{k<N} taken from the evaluation of the stack of
+// decision-independent generators (tz_problem_attach_tube_stack) instead of the collapsed recursion of tz_tube_kernel.
+struct ThetaStackParams {
+  int B, n, m, N, nseg, ntheta;
+  const double* center; const double* radx; const double* radu;     // B x nseg x n, B x nseg x n, B x nseg x m
+  double* theta;                                                    // B x ntheta
+};
+
+__global__ void tz_theta_stack_kernel(ThetaStackParams q) {
+  const int blk = 2 * q.n + q.m;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)q.B * q.N * blk) return;
+  const int c = (int)(gid % blk), k = (int)((gid / blk) % q.N), b = (int)(gid / ((size_t)blk * q.N));
+  double v;
+  if (c < q.n) v = q.center[((size_t)b * q.nseg + k) * q.n + c];
+  else if (c < 2 * q.n) v = q.radx[((size_t)b * q.nseg + k) * q.n + (c - q.n)];
+  else v = q.radu[((size_t)b * q.nseg + k) * q.m + (c - 2 * q.n)];
+  q.theta[(size_t)b * q.ntheta + 2 * q.n + (size_t)k * blk + c] = v;
+}

@@ -191,10 +191,14 @@ struct tz_problem {
   bool chol1 = false;          // single-wave Cholesky overlapped with the predictor's G' product (Tz <= 16; TZ_CHOL1=0 disables)
   bool ksplit = false;         // Gram by k-split (Tz <= TZ_KS_TZ; TZ_KSPLIT=0 keeps the item plan)
   bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_FUSE=0: four kernels per step, same arithmetic)
+  struct tz_genstack* tube_stack = nullptr;   // literal problems: decision-independent generators, evaluated per solve (not owned)
+  DevBuf<double> ts_zeta, ts_c, ts_rx, ts_ru;  int ts_cap = 0;
   int maxr = 1, ncg = 1;
   void (*ipm_fn)(IpmParams) = nullptr;
   DevBuf<unsigned long long> prof_buf, work_buf;
 };
+
+extern "C" int tube_stack_theta(tz_problem* p, int B, const double* d_e0, hipStream_t st);   // literal problems: theta from the attached stack (defined with the K1g entry points)
 
 namespace {
 
@@ -322,6 +326,7 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
     Timer tm(p, K_TUBE);
     TubeParams tp{B, p->n, p->m, p->N, p->pmax, p->ntheta, p->CKpow.p, p->Ttube.p, p->power.p, d_xbar0, d_e0, p->theta.p, p->prestatus.p};
     hipLaunchKernelGGL(tz_tube_kernel, dim3(B), dim3(64), 0, st, tp);
+    if (p->tube_stack) { int rc = tube_stack_theta(p, B, d_e0, st); if (rc) return rc; }
     AffineParams ap{B, p->ntheta, p->nz, p->mi, p->npar, p->q.view(), p->h.view(), p->par.view(), p->par_lo.p, p->par_hi.p,
                     p->theta.p, p->qv.p, p->hv.p, p->prestatus.p};
     size_t total = (size_t)B * (p->nz + p->mi + p->npar);
@@ -537,6 +542,26 @@ int gs_inputs(tz_genstack* g, int B, const double* e0, const double* zeta, int m
 }
 }  // namespace
 
+// evaluation of the whole stack for B trajectories, device pointers, on `st`
+static int gs_eval(tz_genstack* g, int B, const double* de0, const double* dz, double* dc, double* drx, double* dru, hipStream_t st) {
+  const int n = g->n, m = g->m, p = n + m;
+  GenstackParams q{B, n, m, g->N, g->nseg, g->nchunk, g->rec, g->recs_sorted.p, g->chunks.p, g->K.p, de0, dz, g->partial.p};
+  const dim3 grid((unsigned)g->nchunk, (unsigned)((B + 255) / 256));
+  TZ_HIP(hipEventRecord(g->ev0, st));
+  if (g->nchunk > 0) {
+    if (n == 2 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<2, 1>), grid, dim3(256), 0, st, q);
+    else if (n == 4 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<4, 1>), grid, dim3(256), 0, st, q);
+    else if (n == 5 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<5, 1>), grid, dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((tz_genstack_kernel<0, 0>), grid, dim3(256), 0, st, q);
+  }
+  TZ_HIP(hipEventRecord(g->ev1, st));
+  GsReduceParams r{B, n, m, g->N, g->nseg, g->seg_chunk_ptr.p, g->partial.p, g->c0.p, g->cE.p, g->have_cZ ? g->cZ.p : nullptr, de0, dz, dc, drx, dru};
+  const size_t total = (size_t)B * g->nseg * p;
+  hipLaunchKernelGGL(tz_genstack_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+  TZ_HIP(hipGetLastError());
+  return TZ_OK;
+}
+
 int tz_genstack_intervals(tz_genstack* g, int32_t B, const double* e0, const double* zeta,
                           double* centre, double* rad_x, double* rad_u, double* kernel_ms, int mem) {
   if (!g || !e0 || !zeta || !centre || !rad_x || !rad_u) TZ_FAIL(TZ_ERR_INVALID, "null argument");
@@ -552,18 +577,8 @@ int tz_genstack_intervals(tz_genstack* g, int32_t B, const double* e0, const dou
     TZ_HIP(g->o_c.alloc((size_t)B * g->nseg * n)); TZ_HIP(g->o_rx.alloc((size_t)B * g->nseg * n)); TZ_HIP(g->o_ru.alloc((size_t)B * g->nseg * m));
     dc = g->o_c.p; drx = g->o_rx.p; dru = g->o_ru.p;
   }
-  GenstackParams q{B, n, m, g->N, g->nseg, g->nchunk, g->rec, g->recs_sorted.p, g->chunks.p, g->K.p, de0, dz, g->partial.p};
-  const dim3 grid((unsigned)g->nchunk, (unsigned)((B + 255) / 256));
-  TZ_HIP(hipEventRecord(g->ev0, 0));
-  if (n == 2 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<2, 1>), grid, dim3(256), 0, 0, q);
-  else if (n == 4 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<4, 1>), grid, dim3(256), 0, 0, q);
-  else if (n == 5 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<5, 1>), grid, dim3(256), 0, 0, q);
-  else hipLaunchKernelGGL((tz_genstack_kernel<0, 0>), grid, dim3(256), 0, 0, q);
-  TZ_HIP(hipEventRecord(g->ev1, 0));
-  GsReduceParams r{B, n, m, g->N, g->nseg, g->seg_chunk_ptr.p, g->partial.p, g->c0.p, g->cE.p, g->have_cZ ? g->cZ.p : nullptr, de0, dz, dc, drx, dru};
-  const size_t total = (size_t)B * g->nseg * p;
-  hipLaunchKernelGGL(tz_genstack_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, r);
-  TZ_HIP(hipGetLastError());
+  int rc2 = gs_eval(g, B, de0, dz, dc, drx, dru, 0);
+  if (rc2) return rc2;
   if (mem == TZ_MEM_HOST) {
     TZ_HIP(hipMemcpy(centre, dc, (size_t)B * g->nseg * n * sizeof(double), hipMemcpyDeviceToHost));
     TZ_HIP(hipMemcpy(rad_x, drx, (size_t)B * g->nseg * n * sizeof(double), hipMemcpyDeviceToHost));
@@ -575,6 +590,35 @@ int tz_genstack_intervals(tz_genstack* g, int32_t B, const double* e0, const dou
     TZ_HIP(hipEventElapsedTime(&ms, g->ev0, g->ev1));
     *kernel_ms = ms;
   }
+  return TZ_OK;
+}
+
+int tube_stack_theta(tz_problem* p, int B, const double* d_e0, hipStream_t st) {
+  tz_genstack* g = p->tube_stack;
+  const int n = p->n, m = p->m, pq = n + m;
+  if (B > p->ts_cap) {
+    TZ_HIP(p->ts_zeta.alloc((size_t)B * g->N * pq)); TZ_HIP(hipMemset(p->ts_zeta.p, 0, (size_t)B * g->N * pq * sizeof(double)));
+    TZ_HIP(p->ts_c.alloc((size_t)B * g->nseg * n)); TZ_HIP(p->ts_rx.alloc((size_t)B * g->nseg * n)); TZ_HIP(p->ts_ru.alloc((size_t)B * g->nseg * m));
+    p->ts_cap = B;
+  }
+  if (B > g->Bcap) { TZ_HIP(g->partial.alloc((size_t)std::max(g->nchunk, 1) * B * pq)); g->Bcap = B; }
+  int rc = gs_eval(g, B, d_e0, p->ts_zeta.p, p->ts_c.p, p->ts_rx.p, p->ts_ru.p, st);
+  if (rc) return rc;
+  ThetaStackParams q{B, n, m, p->N, g->nseg, p->ntheta, p->ts_c.p, p->ts_rx.p, p->ts_ru.p, p->theta.p};
+  const size_t total = (size_t)B * p->N * (2 * n + m);
+  hipLaunchKernelGGL(tz_theta_stack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q);
+  TZ_HIP(hipGetLastError());
+  return TZ_OK;
+}
+
+int tz_problem_attach_tube_stack(tz_problem* p, tz_genstack* g) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  if (g) {
+    if (g->device != p->device || g->n != p->n || g->m != p->m) TZ_FAIL(TZ_ERR_INVALID, "stack and problem differ in device or dimensions");
+    if (g->nseg < p->N) TZ_FAIL(TZ_ERR_INVALID, "the stack holds %d tubes, the problem needs %d", g->nseg, p->N);
+    p->fuse_enabled = false;                                   // the fused step computes theta in-kernel from the collapsed recursion
+  }
+  p->tube_stack = g;
   return TZ_OK;
 }
 

@@ -164,3 +164,41 @@ def evaluate_host(st: GenStack, e0: np.ndarray, zeta: np.ndarray):
         c = st.c0[k] + st.cE[k] @ e0 + np.einsum("jic,jc->i", st.cZ[k], zeta)
         out.append((c, np.abs(val[sl]).sum(axis=0), np.abs(val[sl] @ st.K.T).sum(axis=0)))
     return out
+
+
+def restrict_to_e0(st: GenStack, nseg: int) -> GenStack:
+    """The sub-stack of the generators that do not depend on a decision variable (constant or e0-sourced), tubes 0 .. nseg-1: what
+    the device evaluates per solve for the literal problem (centres C_K^p e0 + c0 and the numeric part of the radii)."""
+    keep, ptr = [], [0]
+    for k in range(nseg):
+        for g in range(int(st.seg_ptr[k]), int(st.seg_ptr[k + 1])):
+            if st.src[g] <= 0:
+                keep.append(g)
+        ptr.append(len(keep))
+    keep = np.asarray(keep, dtype=np.int64)
+    return GenStack(st.n, st.m, st.N, nseg, np.asarray(ptr, dtype=np.int64), st.src[keep], st.m0[keep], st.M[keep],
+                    st.c0[:nseg], st.cE[:nseg], np.zeros_like(st.cZ[:nseg]), st.K)
+
+
+def count_generators(gK: int, gD: int, gW: int, N: int, k0: Optional[int] = None, nseg: Optional[int] = None):
+    """Generator counts of Ze[0 .. nseg-1] and how many of them depend on a decision variable, from the recurrences of
+    ``build_stack`` alone (nothing is materialised): (total per tube, decision-dependent per tube)."""
+    nseg = max(N, 2) if nseg is None else nseg
+    t1 = [(gK + 1) * 2 - 1]                          # MdataK * <e0, [0]>: (gamma + 1)(g + 1) - 1 with g = 1
+    zn = gD + 1 + gW                                 # Mdelta * <zeta, [0]> + W : (gD + 1) * 2 - 1 + gW ... the centre column is zero but kept
+    zn = (gD + 1) * 2 - 1 + gW
+    tot, dec = [1], [0]
+    for k in range(nseg - 1):
+        if k0 is None:
+            t1.append((gK + 1) * (t1[-1] + 1) - 1)
+            noise = zn
+            for _ in range(1, k):
+                noise = (gK + 1) * (noise + 1) - 1 + zn
+        else:
+            t1.append(t1[-1] if k > k0 else (gK + 1) * (t1[-1] + 1) - 1)
+            noise = zn
+            for _ in range(1, min(k, k0)):
+                noise = (gK + 1) * (noise + 1) - 1 + zn
+        tot.append(t1[k] + noise)
+        dec.append(noise)                            # upper bound: the W columns inside are constants
+    return tot, dec

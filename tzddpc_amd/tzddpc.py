@@ -28,6 +28,9 @@ class _Value:
         self.value = value
 
 
+TZ_MAX_VARIABLES = 256          # decision variables of the device solver (LDS-resident Newton system, tz_problem_create)
+
+
 class TubeZonotope:
     """What ``solve`` returns in 4th position: the reference hands back the CVXZonotope ``Ze[1]``
     whose ``.Z.value`` is ``[center | generators]`` (``tzddpc/tzddpc.py:377``,
@@ -109,7 +112,7 @@ class TZDDPC(object):
         if getattr(self, "_native", None) is not None:
             self._native.close()
         self._native = None
-        for name in ("_gs_ze1",):
+        for name in ("_gs_ze1", "_gs_tube"):
             if getattr(self, name, None) is not None:
                 getattr(self, name).close()
             setattr(self, name, None)
@@ -214,19 +217,39 @@ class TZDDPC(object):
         n, m = self.dim_x, self.dim_u
         DK = self.MdataK.single_entry_magnitudes()
         Dd = self.Mdelta.single_entry_magnitudes()
-        if DK is None or Dd is None:
-            raise StructureError(
-                "MdataK / Mdelta have generators with more than one non-zero entry; only the Girard order-1 boxes that "
-                "build_zonotopes_theta produces (reference tzddpc/tzddpc.py:126-128) are supported by the collapsed tube path")
         if np.abs(self.Mdelta.center).max(initial=0.0) != 0.0:
             raise StructureError("Mdelta must have a zero center (reference tzddpc/tzddpc.py:122-123)")
         A, B = self.Mdata.center[:, :n], self.Mdata.center[:, n:]                             # :163
         Xi, Ui = self.zonotopes.X.interval, self.zonotopes.U.interval
         W = self.zonotopes.W
+        stack = None
+        epigraph = str(solver_kwargs.pop("epigraph", "auto"))
+        if DK is None or Dd is None:
+            # dense generators (reduce(order > 1), or no reduction): no collapse -- the LITERAL problem, one epigraph variable per
+            # decision-dependent generator entry; feasible while it fits the LDS-resident Newton system (<= 256 variables)
+            from .genstack import build_stack, count_generators
+            tot, dec = count_generators(self.MdataK.num_generators, self.Mdelta.num_generators, W.num_generators, int(horizon), k0,
+                                        nseg=int(horizon))
+            if sum(dec) * (n + m) > 8 * TZ_MAX_VARIABLES or sum(tot) > 4_000_000:
+                raise StructureError(
+                    f"MdataK / Mdelta have dense generators and the literal problem needs up to {sum(dec) * (n + m)} epigraph variables "
+                    f"({sum(tot)} generators in the tubes); the device solver holds {TZ_MAX_VARIABLES} variables.  Use the Girard order-1 "
+                    "boxes of build_zonotopes_theta (reference tzddpc/tzddpc.py:126-128), a shorter horizon or a smaller k0")
+            stack = build_stack(self.MdataK, self.Mdelta, self.theta.K, W, n, m, int(horizon), k0, nseg=int(horizon))
+            ndec = int(np.count_nonzero(stack.src > 0)) * (n + m)
+            if ndec + int(horizon) * m > 4 * TZ_MAX_VARIABLES:
+                raise StructureError(
+                    f"MdataK / Mdelta have dense generators and the literal problem needs about {ndec + int(horizon) * m} variables "
+                    f"(one per decision-dependent generator entry); the device solver holds {TZ_MAX_VARIABLES}.  Use the Girard order-1 "
+                    "boxes of build_zonotopes_theta (reference tzddpc/tzddpc.py:126-128), a shorter horizon or a smaller k0")
         qp = build_parametric_qp(A, B, self.MdataK.center, DK, Dd, self.theta.K, W.center, W.generators,
                                  Xi.left_limit, Xi.right_limit, Ui.left_limit, Ui.right_limit,
-                                 int(horizon), build_loss, build_constraints, k0,
-                                 epigraph=str(solver_kwargs.pop("epigraph", "auto")))
+                                 int(horizon), build_loss, build_constraints, k0, epigraph=epigraph, literal=stack)
+        if stack is not None and qp.nz > TZ_MAX_VARIABLES:
+            raise StructureError(
+                f"MdataK / Mdelta have dense generators and the literal problem has {qp.nz} variables (one per decision-dependent "
+                f"generator entry); the device solver holds {TZ_MAX_VARIABLES}.  Use the Girard order-1 boxes of build_zonotopes_theta "
+                "(reference tzddpc/tzddpc.py:126-128), a shorter horizon or a smaller k0")
         self.qp = qp
         self.horizon = int(horizon)
         self.k0 = k0
@@ -235,6 +258,9 @@ class TZDDPC(object):
         self._drop_native()
         self._native, info = self._native_from_qp(qp, solver_kwargs)
         self._elim, self._scal, self._row_of = info["elim"], info["scal"], info["row_of"]
+        if stack is not None:                           # decision-independent generators: evaluated per solve on the device (K1g)
+            self._gs_tube = native.GenStack(self.device, qp.estack)
+            self._native.attach_tube_stack(self._gs_tube)
         self.warm_shift_policy = self._choose_warm_shift(warm_shift, A, B)
         self.warm_push_gain = self._choose_warm_push(warm_gain, A, B)
         self.problem_full = self._native
