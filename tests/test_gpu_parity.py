@@ -803,7 +803,7 @@ def test_warm_push_calibration_keeps_parity(built):
     needs no more factorisations than the default."""
     from tzddpc_amd.dist import vertex_noise
     ctl, (A, B, zon) = common.gpu_controller("dim5_n20")
-    assert ctl.warm_push_gain in (1.0, 0.1, 0.01, 0.003)
+    assert ctl.warm_push_gain in (1.0, 0.3, 0.1, 0.03, 0.01, 0.003, 0.001)
     Bn, T = 32, 16
     noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
     x0 = np.tile(zon.X0.center, (Bn, 1))

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Callable, List, Optional, Tuple
 
+import os
+
 import numpy as np
 
 from . import native
@@ -261,6 +263,8 @@ class TZDDPC(object):
         if stack is not None:                           # decision-independent generators: evaluated per solve on the device (K1g)
             self._gs_tube = native.GenStack(self.device, qp.estack)
             self._native.attach_tube_stack(self._gs_tube)
+        # plant of the calibration loops: the identified centre (a sampled member of the boxed Mdata was tried: its mismatch is far
+        # larger than a real plant's and turned the preference around on the double integrators)
         self.warm_shift_policy = self._choose_warm_shift(warm_shift, A, B)
         self.warm_push_gain = self._choose_warm_push(warm_gain, A, B)
         self.problem_full = self._native
@@ -350,9 +354,12 @@ class TZDDPC(object):
 
     def _choose_warm_push(self, mode, A_model, B_model) -> float:
         """Gain of the push that re-centres a warm start (``tz_problem_set_warm_push``): a number, or ``"auto"`` -- the same short
-        simulated closed loop as for the shift policy is run for a few gains and the one with the fewest factorisations is kept if
-        it wins by 3 % (5-dim example: 6.4 -> 4.0 factorisations per step at 0.003; double integrators: no difference -> 1)."""
+        simulated closed loop as for the shift policy is run for seven gains between 1 and 0.001; if the best beats the default 1 by
+        3 % the largest gain within 1 % of the best is kept (5-dim example: 6.4 -> 4.2 factorisations per step in steady state;
+        double integrators: the steady state does not care, the transient from X0 needs ~10 % fewer)."""
         nat = self._native
+        if mode == "auto" and os.environ.get("TZ_WARM_GAIN"):
+            mode = float(os.environ["TZ_WARM_GAIN"])           # experiment switch, like the library's other TZ_* overrides
         if mode != "auto":
             gain = float(mode)
         else:
@@ -362,15 +369,20 @@ class TZDDPC(object):
             rng = np.random.default_rng(12345)
             noise = Wv[rng.integers(0, Wv.shape[0], size=(Bn, T))]
             x0 = np.tile(np.asarray(zon.X0.center, float), (Bn, 1))
-            best, gain = None, 1.0
-            for cand in (1.0, 0.1, 0.01, 0.003):
+            cands = (1.0, 0.3, 0.1, 0.03, 0.01, 0.003, 0.001)
+            work = {}
+            for cand in cands:
                 nat.set_warm_push(1e-8, cand)
                 nat.timing_enable(True)
                 _, _, _, status = nat.simulate_batch(x0, noise, A_model, B_model)
-                work = nat.work_get()["factorizations"] + (10 ** 9 if np.any(status != 0) else 0)
+                work[cand] = nat.work_get()["factorizations"] + (10 ** 9 if np.any(status != 0) else 0)
                 nat.timing_enable(False)
-                if best is None or work < 0.97 * best:
-                    best, gain = work, cand
+            if os.environ.get("TZ_CALIB_DEBUG"):
+                print("warm push calibration (factorisations):", work)
+            least = min(work.values())
+            gain = 1.0
+            if least < 0.97 * work[1.0]:                      # the default stays unless something wins by 3 %
+                gain = max(c for c in cands if work[c] <= 1.01 * least)     # ... then the largest gain within 1 % of the best
         nat.set_warm_push(1e-8, gain)
         return gain
 
