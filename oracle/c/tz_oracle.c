@@ -42,6 +42,7 @@ typedef struct tzo_desc {
   const int32_t *shift_var, *shift_row;   /* receding-horizon shift of the warm start: source variable (nz) / two-sided row (nc) */
   int32_t shift_policy;           /* 0 never, 1 always, k >= 2: after a step of >= k iterations and while the shifted steps that
                                    * follow take one iteration (tz_problem_set_warm_shift) */
+  int32_t shift_quiet;            /* k >= 2: the shifted regime is left after this many one-iteration shifted steps in a row (0: never) */
 } tzo_desc;
 
 typedef struct {
@@ -395,8 +396,10 @@ static int tzo_simulate_core(const tzo_desc* d, int B, int T, const double* x0, 
       for (int t = 0; t < T; ++t) {
         int32_t st, it; double c;
         int wmode = prev_ok ? ((t & 7) ? 2 : 1) : 0;               /* x / s / lam (and G x) of the previous step live on in wk */
-        if (prev_ok && S->srow && (d->shift_policy == 1 || (d->shift_policy >= 2 && (prev_it >= d->shift_policy || (was_shifted && prev_it <= 1))))) wmode = 3;
-        was_shifted = (wmode == 3);
+        const int quiet_run = was_shifted && prev_it <= 1;
+        const int nquiet = quiet_run ? was_shifted : 0;              /* was_shifted = 1 + quiet shifted steps so far */
+        if (prev_ok && S->srow && (d->shift_policy == 1 || (d->shift_policy >= 2 && (prev_it >= d->shift_policy || (quiet_run && (d->shift_quiet == 0 || nquiet <= d->shift_quiet)))))) wmode = 3;
+        was_shifted = (wmode == 3) ? 1 + nquiet : 0;
         solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk, wmode);
         prev_it = it;
         if (iters_out) iters_out[(size_t)b * T + t] = it;

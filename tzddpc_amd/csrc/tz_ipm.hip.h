@@ -54,7 +54,8 @@ struct IpmParams {
   int ntube;                  // doubles of tube tables kept in LDS by fused launches: (pmax + 1) n n + pmax (n + m) n
   int shift_policy;           // receding-horizon shift of the warm start: 0 never, 1 always, k >= 2 after a step of >= k iterations
                               // and for as long as the shifted steps that follow finish in one iteration
-  int* shift_state;           // per trajectory: was the last warm start shifted (carried across launches)
+  int* shift_state;           // per trajectory: 0 = the last warm start was not shifted, 1 + q = it was, after q quiet (one-iteration) shifted steps
+  int shift_quiet;            // k >= 2 policies: leave the shifted regime after this many quiet steps in a row (0: never)
   const int* sx; const int* sr; const double* sxs; const double* sls;   // source variable / row and rescaling, see tz_problem_desc
   // problems with more than 64 variables (tz_tt.hip.h): H in the tile-triangle layout, TS doubles per tile, blocked Gram plan
   int TS, ntile, gu;       // gu: tiles per side of a unit of the blocked Gram
@@ -1115,8 +1116,10 @@ retry_solve:
     // the previous solution, optionally moved one step along the horizon (v_k <- v_{k+1} ...: better in a transient, a matter of
     // the problem otherwise -- tz_problem_set_warm_shift)
     const int prev_it = (step == 0) ? pk.iters[b] : it;
-    const bool shifted = pk.shift_policy == 1 || (pk.shift_policy >= 2 && (prev_it >= pk.shift_policy || (was_shifted != 0 && prev_it <= 1)));
-    was_shifted = shifted ? 1 : 0;
+    const bool quiet_run = was_shifted != 0 && prev_it <= 1;
+    const int nquiet = quiet_run ? was_shifted : 0;                       // was_shifted - 1 quiet steps so far, this one included: was_shifted
+    const bool shifted = pk.shift_policy == 1 || (pk.shift_policy >= 2 && (prev_it >= pk.shift_policy || (quiet_run && (pk.shift_quiet == 0 || nquiet <= pk.shift_quiet))));
+    was_shifted = shifted ? 1 + nquiet : 0;
     if (src == 1) {
       if (shifted) {
         for (int c = t; c < nz; c += TZ_THREADS) xv[c] = pk.x[(size_t)b * nz + pk.sx[c]] * pk.sxs[c];

@@ -154,6 +154,7 @@ struct tz_problem {
   DevBuf<int> power, row_of, klist, item_ptr, smask, shift_var, shift_row;
   DevBuf<double> shift_xs, shift_ls;
   int shift_policy = 0;        // 0 never, 1 always, k >= 2: after a step of >= k iterations (tz_problem_set_warm_shift)
+  int shift_quiet = 16;        // leave the shifted regime after this many one-iteration shifted steps (0: never)
   bool have_shift = false;
   DevBuf<IpmItem> items;
   DevCsr q, h, par;
@@ -279,7 +280,7 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.work = p->timing ? p->work_buf.p : nullptr;
   ip.TS = p->TS; ip.ntile = p->ntile; ip.gu = p->gu; ip.gunits = p->gunits.p; ip.gunit_ptr = p->gunit_ptr.p;
   ip.nklist = p->nklist; ip.nP = p->nP; ip.ksplit = p->ksplit ? 1 : 0; ip.chol1 = p->chol1 ? 1 : 0; ip.ntube = p->ntube;
-  ip.shift_policy = p->have_shift ? p->shift_policy : 0;
+  ip.shift_policy = p->have_shift ? p->shift_policy : 0; ip.shift_quiet = p->shift_quiet;
   ip.shift_state = p->shift_state.p;
   ip.sx = p->shift_var.p; ip.sr = p->shift_row.p; ip.sxs = p->shift_xs.p; ip.sls = p->shift_ls.p;
   ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
@@ -966,6 +967,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (const char* e = getenv("TZ_WARM")) { p->warm_enabled = (e[0] != '0'); }
   if (const char* e = getenv("TZ_FUSE")) { p->fuse_enabled = (e[0] != '0'); }
   if ((size_t)p->pmax * p->n > p->hsize) p->fuse_enabled = false;   // tube scratch borrows the factor storage
+  if (const char* e = getenv("TZ_SHIFT_QUIET")) p->shift_quiet = atoi(e);
   if (const char* e = getenv("TZ_WARM_FLOOR")) { double v = atof(e); if (v > 0) p->warm_floor = v; }
   if (const char* e = getenv("TZ_WARM_GAIN")) p->warm_gain = atof(e);
   if (const char* e = getenv("TZ_MU_FACTOR")) p->mu_factor = atof(e);
@@ -1148,6 +1150,13 @@ int tz_problem_set_warm_shift(tz_problem* p, int32_t policy) {
   if (policy < 0) TZ_FAIL(TZ_ERR_INVALID, "policy must be >= 0");
   if (policy != 0 && !p->have_shift) TZ_FAIL(TZ_ERR_INVALID, "the problem was created without shift maps");
   p->shift_policy = policy;
+  return TZ_OK;
+}
+
+int tz_problem_set_warm_quiet(tz_problem* p, int32_t quiet_steps) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  if (quiet_steps < 0) TZ_FAIL(TZ_ERR_INVALID, "quiet_steps must be >= 0");
+  p->shift_quiet = quiet_steps;
   return TZ_OK;
 }
 
