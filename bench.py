@@ -276,7 +276,10 @@ def main():
         elapsed = windows[med]
         fact_per_launch = facts[med]
         iters_mean = facts[med] / max(solves[med], 1)
-        flop_per_launch = nat.alg_flops["per_factorization"] * fact_per_launch
+        # every trajectory-step also evaluates the stopping test of its starting point once more than it factorises (a warm start
+        # that is already optimal costs exactly this and no factorisation): residual products P x, G'lambda, G x
+        flop_per_test = nat.alg_flops["p_products"] + 0.5 * nat.alg_flops["g_products"]
+        flop_per_launch = nat.alg_flops["per_factorization"] * fact_per_launch + flop_per_test * solves[med]
         avg_ms = float(np.median(kern_ms))
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
         sysname, _, _, _, k0, _, desc = CONFIGS[args.config]
@@ -303,10 +306,12 @@ def main():
                          "kernel": "tz_ipm_kernel", "avg_launch_ms": avg_ms, "launch_ms_all": [round(v, 5) for v in kern_ms], "launches": R,
                          "flop_per_launch": flop_per_launch,
                          "flop_per_factorization": nat.alg_flops["per_factorization"],
+                         "flop_per_stopping_test": flop_per_test, "factorizations_per_launch": fact_per_launch, "trajectory_steps_per_launch": solves[med],
                          "dense_flop_per_factorization": nat.alg_flops["dense_per_factorization"],
                          "note": "algorithmic f64 flops of one interior-point factorisation counted on the non-zeros of G (sparse outer products "
-                                 "for G'WG, Cholesky, four G/G' products, two solve pairs, P x) x factorisations counted on the device; the dense "
-                                 "count is given beside it; prologue / recovery / plant work of the fused step is not counted; launch time = "
+                                 "for G'WG, Cholesky, four G/G' products, two solve pairs, P x) x factorisations counted on the device, plus one "
+                                 "stopping test (P x, G'lambda, G x) per trajectory-step -- a warm start that is already optimal costs only that; "
+                                 "the dense count is given beside it; tube / recovery / plant work of the fused step is not counted; launch time = "
                                  "median over the repeats of the HIP-event time of the one timed launch"},
         }
         tb, tinfo = archived_traffic(args.config, ctl.qp.nz, nat.mi, Bl, K)

@@ -270,8 +270,9 @@ int tz_problem_set_warm_shift(tz_problem* p, int32_t policy);
  * step: +4.7 % on the double integrator N=40 in steady state, measured); leaving earlier costs iterations in the late transient. */
 int tz_problem_set_warm_quiet(tz_problem* p, int32_t quiet_steps);
 
-/* Warm-started steps re-derive the slacks for the new right-hand side and push slacks and multipliers into the cone by
- *     sigma = max(floor, gain * (largest violation of the new rows by the previous solution))      (scaled units).
+/* Warm-started steps re-derive the slacks for the new right-hand side and push the point into the cone: with
+ *     sigma = max(floor, gain * (largest violation of the new rows by the previous solution))      (scaled units)
+ * slack >= sigma and multiplier >= sigma^2 / slack (onto the central path of mu = sigma^2; inactive rows keep multipliers ~ 0).
  * The gain that costs the fewest interior-point iterations depends on the problem (measured on MI355X: the 5-dim example needs
  * 6.4 factorisations per step at gain 1 and 4.0 at 0.003, the pulley is best near 1, the double integrators do not care) -- the
  * Python layer calibrates it together with the shift policy.  Defaults: floor 1e-8, gain 1. */

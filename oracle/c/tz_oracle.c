@@ -18,6 +18,7 @@
  * OpenMP over trajectories (threads argument); scalar code otherwise.
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -187,7 +188,8 @@ static double max_step(int n, const double* v, const double* dv) {
 
 /* status: 0 solved, 1 max_iter, 2 numerical, 3 infeasible */
 /* warm != 0: x / lam hold the previous closed-loop step's solution of this trajectory; the slacks are re-derived for the
- * new h and (s, lam) pushed into the cone by max(warm_floor, warm_gain * largest violation of the new rows). */
+ * new h and (s, lam) pushed into the cone: sig = max(warm_floor, warm_gain * largest violation of the new rows), s >= sig,
+ * lam >= sig^2 / s. */
 static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const double* h, double* x, double* s, double* lam, int* iters, double* wk, int warm) {
   /* warm == 2: as warm == 1 and gx (G x of the starting point) is still valid in the work area from the previous step;
    * warm == 3: the previous (x, lambda) moved one step along the horizon first (values move unscaled, hence the D / E ratios) */
@@ -208,7 +210,9 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
       viol = fmax(viol, gx[r] - h[r]);
     }
     double sig = fmax(d->warm_floor, d->warm_gain * viol);
-    for (int r = 0; r < mi; ++r) { s[r] = fmax(h[r] - gx[r], sig); lam[r] = fmax(lam[r], sig); }
+    /* slack at least sig; multiplier at least sig^2 / s: the pair is pushed onto the central path of mu = sig^2 where it was
+     * below it, and an inactive row (large slack, multiplier ~ 0) keeps a multiplier ~ 0 instead of being lifted to sig */
+    for (int r = 0; r < mi; ++r) { s[r] = fmax(h[r] - gx[r], sig); lam[r] = fmax(lam[r], sig * sig / s[r]); }
   } else {
   for (int r = 0; r < mi; ++r) w[r] = 1.0;
   form_H(S, w, d->reg, H, GW);
@@ -236,6 +240,7 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
     for (int r = 0; r < mi; ++r) { rp[r] = gx[r] + s[r] - h[r]; nrp = fmax(nrp, fabs(rp[r])); mu += s[r] * lam[r]; }
     mu /= mi; nrd /= scd; nrp /= scp;
     *iters = it;
+    if (getenv("TZO_TRACE")) fprintf(stderr, "  it %d mu %.3e rd %.3e rp %.3e warm %d\n", it, mu, nrd, nrp, warm);
     if (nrd <= d->tol && nrp <= d->tol && mu <= d->mu_tol) return 0;
     if (mu <= 1e-3 * d->mu_tol) return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 2;   /* mu collapsed before the residuals: numerical */
     if (!(mu == mu) || !(nrd == nrd) || mu > 1e200) return 2;
@@ -258,12 +263,14 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
       continue;
     }
     double sigma = muaff / mu; sigma = sigma * sigma * sigma;
+    if (getenv("TZO_TRACE")) fprintf(stderr, "     affine ap %.4f ad %.4f muaff/mu %.3e sigma %.3e\n", ap, ad, muaff / mu, sigma);
     /* corrector */
     for (int r = 0; r < mi; ++r) { rc[r] = s[r] * lam[r] + ds[r] * dl[r] - sigma * mu; t1[r] = (-rc[r] + lam[r] * rp[r]) / s[r]; }
     for (int c = 0; c < nz; ++c) { double a = -rd[c]; for (int r = 0; r < mi; ++r) a -= S->G[r * nz + c] * t1[r]; dx[c] = a; }
     chol_solve(nz, H, dx);
     for (int r = 0; r < mi; ++r) { double a = 0; for (int c = 0; c < nz; ++c) a += S->G[r * nz + c] * dx[c]; gdx[r] = a; ds[r] = -rp[r] - a; dl[r] = (-rc[r] - lam[r] * ds[r]) / s[r]; }
     double alpha = fmin(1.0, d->step_frac * fmin(max_step(mi, s, ds), max_step(mi, lam, dl)));
+    if (getenv("TZO_TRACE")) fprintf(stderr, "     corrected step: ap %.4f ad %.4f\n", max_step(mi, s, ds), max_step(mi, lam, dl));
     for (int c = 0; c < nz; ++c) x[c] += alpha * dx[c];
     for (int r = 0; r < mi; ++r) { s[r] += alpha * ds[r]; lam[r] += alpha * dl[r]; gx[r] += alpha * gdx[r]; }
   }

@@ -73,7 +73,7 @@ def lib():
 
 
 class COracle:
-    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999, warm_floor=1e-8, warm_gain=1.0, mu_factor=0.3, aff_thr=0.99, aff_mu=1e-3, shift_policy=0, shift_maps=None, shift_quiet=16):
+    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999, warm_floor=1e-8, warm_gain=1.0, mu_factor=0.01, aff_thr=0.99, aff_mu=1e-3, shift_policy=0, shift_maps=None, shift_quiet=16):
         self.qp = qp
         self._keep = []
         d = Desc()

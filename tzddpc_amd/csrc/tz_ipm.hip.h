@@ -1143,9 +1143,10 @@ retry_solve:
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
     tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red, rpar);      // also the scales of the stopping test
     const double sig = fmax(pk.warm_floor, pk.warm_gain * viol);
-    TZ_ROWS(k, r) {
-      s_[k] = fmax(TZ_H(k, r) - TZ_GX(k, r), sig);
-      l_[k] = fmax(l_[k], sig);
+    const double sig2 = sig * sig;
+    TZ_ROWS(k, r) {                  // slack >= sig, multiplier >= sig^2 / slack: onto the central path of mu = sig^2 where the pair was
+      s_[k] = fmax(TZ_H(k, r) - TZ_GX(k, r), sig);           // below it; an inactive row keeps its multiplier ~ 0 instead of being
+      l_[k] = fmax(l_[k], sig2 * tz_recip(s_[k]));           // lifted to sig (which alone set mu ~ sig * mean slack: 6 more iterations)
     }
   }
   if (!warm) {

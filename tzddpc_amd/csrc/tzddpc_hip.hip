@@ -180,7 +180,7 @@ struct tz_problem {
   int lastB = 0;
   bool prof = false;
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
-  double warm_floor = 1e-8, warm_gain = 1.0, mu_factor = 0.3, aff_thr = 0.99, aff_mu = 1e-3;
+  double warm_floor = 1e-8, warm_gain = 1.0, mu_factor = 0.01, aff_thr = 0.99, aff_mu = 1e-3;
   bool warm_enabled = true;
   int ntube = 0;
   bool tt = false;             // tile-triangle layout / blocked Gram / two-phase Cholesky (nz > 64 or more than 1024 rows)
