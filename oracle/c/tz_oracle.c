@@ -39,6 +39,7 @@ typedef struct tzo_desc {
   int32_t max_iter; double tol, reg, step_frac;
   double warm_floor, warm_gain;   /* closed-loop warm start (tzo_simulate_batch): see ipm() */
   double mu_tol;                  /* complementarity target (<= tol) */
+  double res_tol;                 /* residual tolerance of the stopping test (>= tol) */
   double aff_thr, aff_mu;         /* predictor step taken as the step when it is (nearly) full and leaves mu_aff <= aff_mu mu */
   const int32_t *shift_var, *shift_row;   /* receding-horizon shift of the warm start: source variable (nz) / two-sided row (nc) */
   int32_t shift_policy;           /* 0 never, 1 always, k >= 2: after a step of >= k iterations and while the shifted steps that
@@ -241,8 +242,9 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
     mu /= mi; nrd /= scd; nrp /= scp;
     *iters = it;
     if (getenv("TZO_TRACE")) fprintf(stderr, "  it %d mu %.3e rd %.3e rp %.3e warm %d\n", it, mu, nrd, nrp, warm);
-    if (nrd <= d->tol && nrp <= d->tol && mu <= d->mu_tol) return 0;
-    if (mu <= 1e-3 * d->mu_tol) return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 2;   /* mu collapsed before the residuals: numerical */
+    if (nrd <= d->res_tol && nrp <= d->res_tol && mu <= d->mu_tol) return 0;
+    if (mu <= 1e-3 * d->mu_tol && !(it == 0 && warm))       /* mu collapsed before the residuals: numerical (a warm start may BEGIN */
+      return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 2;   /* there: its first Newton step is what removes the residuals) */
     if (!(mu == mu) || !(nrd == nrd) || mu > 1e200) return 2;
     for (int r = 0; r < mi; ++r) w[r] = lam[r] / s[r];
     form_H(S, w, d->reg, H, GW);

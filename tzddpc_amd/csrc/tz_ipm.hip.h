@@ -49,6 +49,7 @@ struct IpmParams {
   double mu_floor, tol_loose, step_frac_retry;   // 1e-3 mu_tol, 1e3 tol, min(step_frac, 0.99): formed on the host (uniform f64 expressions
                               // have no scalar ALU: the compiler hoists them out of the step loop into vector registers and spills them)
   double mu_tol;              // complementarity target (<= tol): the distance to the solution of a degenerate problem goes like sqrt(mu)
+  double tol_res;             // residual tolerance of the stopping test (>= tol: what the reference's conic solvers ask of feasibility)
   int warm_steps;             // multi-step launches: step k+1 starts from the solution of step k
   int nell;                   // max(eg.VL, et.VL)
   int ntube;                  // doubles of tube tables kept in LDS by fused launches: (pmax + 1) n n + pmax (n + m) n
@@ -1212,7 +1213,8 @@ retry_solve:
     const double mu = sl * pi.inv_mi;
     nrp *= tz_recip(red[13]);
     if (!(mu == mu) || !(nrp == nrp) || mu > 1e200) { status = 2; break; }
-    if ((nrp <= pi.tol && mu <= pi.mu_tol) || mu <= pi.mu_floor) {
+    const bool fresh_warm = (it == 0) && warm;     // a warm start may BEGIN below mu_floor: its first Newton step is what removes the residuals
+    if ((nrp <= pi.tol_res && mu <= pi.mu_tol) || (mu <= pi.mu_floor && !fresh_warm)) {
       exact_rd();
       double e1 = 0, e2 = 0, e3 = 0;
       for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
@@ -1220,8 +1222,8 @@ retry_solve:
       const double nrd = e1 * tz_recip(red[12]);
       TZ_STAMP(PH_GEMVT);
       if (!(nrd == nrd)) { status = 2; break; }
-      if (nrd <= pi.tol && nrp <= pi.tol && mu <= pi.mu_tol) { status = 0; px_in_part = true; break; }
-      if (mu <= pi.mu_floor) { status = (nrd <= pi.tol_loose && nrp <= pi.tol_loose) ? 0 : 2; px_in_part = true; break; }   // mu collapsed before the residuals: numerical
+      if (nrd <= pi.tol_res && nrp <= pi.tol_res && mu <= pi.mu_tol) { status = 0; px_in_part = true; break; }
+      if (mu <= pi.mu_floor && !fresh_warm) { status = (nrd <= pi.tol_loose && nrp <= pi.tol_loose) ? 0 : 2; px_in_part = true; break; }   // mu collapsed before the residuals: numerical
     }
     // Newton matrix.  is = 1/s, il = 1/lambda are the only two divisions per row and iteration.
     TZ_ROWS(k, r) { is_[k] = tz_recip(s_[k]); il_[k] = tz_recip(l_[k]); w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }

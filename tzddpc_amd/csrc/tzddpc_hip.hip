@@ -180,7 +180,7 @@ struct tz_problem {
   int lastB = 0;
   bool prof = false;
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
-  double warm_floor = 1e-8, warm_gain = 1.0, mu_factor = 0.01, aff_thr = 0.99, aff_mu = 1e-3;
+  double warm_floor = 1e-8, warm_gain = 1.0, mu_factor = 1e-3, res_factor = 100.0, aff_thr = 0.99, aff_mu = 1e-3;
   bool warm_enabled = true;
   int ntube = 0;
   bool tt = false;             // tile-triangle layout / blocked Gram / two-phase Cholesky (nz > 64 or more than 1024 rows)
@@ -274,7 +274,7 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.P = p->P.p; ip.Gp = p->Gp.p; ip.items = p->items.p; ip.item_ptr = p->item_ptr.p; ip.klist = p->klist.p; ip.smask = p->smask.p; ip.eg = p->eg.view(); ip.et = p->et.view(); ip.nell = p->nell;
   ip.q = p->qv.p; ip.h = p->hv.p; ip.prestatus = p->prestatus.p; ip.x = p->x.p; ip.s = p->s.p; ip.lam = p->lam.p;
   ip.status = d_status; ip.iters = d_iters ? d_iters : p->iters.p;
-  ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac; ip.mu_tol = p->tol * p->mu_factor;
+  ip.max_iter = p->max_iter; ip.tol = p->tol; ip.reg = p->reg; ip.step_frac = p->step_frac; ip.mu_tol = p->tol * p->mu_factor; ip.tol_res = p->tol * p->res_factor;
   ip.inv_mi = 1.0 / p->mi; ip.mu_floor = 1e-3 * ip.mu_tol; ip.tol_loose = 1e3 * p->tol; ip.step_frac_retry = std::min(p->step_frac, 0.99);
   ip.prof = p->prof ? p->prof_buf.p : nullptr;
   ip.work = p->timing ? p->work_buf.p : nullptr;
@@ -971,6 +971,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (const char* e = getenv("TZ_WARM_FLOOR")) { double v = atof(e); if (v > 0) p->warm_floor = v; }
   if (const char* e = getenv("TZ_WARM_GAIN")) p->warm_gain = atof(e);
   if (const char* e = getenv("TZ_MU_FACTOR")) p->mu_factor = atof(e);
+  if (const char* e = getenv("TZ_RES_FACTOR")) p->res_factor = atof(e);
   if (const char* e = getenv("TZ_AFF_THR")) p->aff_thr = atof(e);
   if (const char* e = getenv("TZ_AFF_MU")) p->aff_mu = atof(e);
   if (const char* e = getenv("TZ_STEP_FRAC")) { double v = atof(e); if (v > 0 && v < 1) p->step_frac = v; }
