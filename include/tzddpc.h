@@ -270,6 +270,13 @@ int tz_problem_set_warm_shift(tz_problem* p, int32_t policy);
  * step: +4.7 % on the double integrator N=40 in steady state, measured); leaving earlier costs iterations in the late transient. */
 int tz_problem_set_warm_quiet(tz_problem* p, int32_t quiet_steps);
 
+/* Stopping test of the interior point, relative to the `tol` of the descriptor: scaled residuals <= res_factor * tol and
+ * complementarity mu <= mu_factor * tol (defaults 100 and 1e-3: 1e-8 / 1e-13 at tol = 1e-10).  The distance to the solution of a
+ * degenerate problem goes like sqrt(mu), so mu_factor is what carries the accuracy of the closed loop; how small it has to be
+ * depends on the problem (double integrator N = 80: 1e-3 for 2e-8, LP-type losses: 0.3 is already at 3e-9) -- the Python layer
+ * picks the loosest factor that keeps a simulated closed loop within 2e-8 of the tightest one (TZDDPC.mu_factor). */
+int tz_problem_set_stopping(tz_problem* p, double res_factor, double mu_factor);
+
 /* Warm-started steps re-derive the slacks for the new right-hand side and push the point into the cone: with
  *     sigma = max(floor, gain * (largest violation of the new rows by the previous solution))      (scaled units)
  * slack >= sigma and multiplier >= sigma^2 / slack (onto the central path of mu = sigma^2; inactive rows keep multipliers ~ 0).

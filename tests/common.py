@@ -159,4 +159,5 @@ def c_oracle_for(ctl, **kw):
     from tzddpc_amd.builder import horizon_shift
     pol = kw.pop("shift_policy", ctl.warm_shift_policy)
     kw.setdefault("warm_gain", float(getattr(ctl, "warm_push_gain", 1.0)))
+    kw.setdefault("mu_factor", float(getattr(ctl, "mu_factor", 1e-3)))
     return COracle(ctl.qp, shift_policy=pol, shift_maps=horizon_shift(ctl.qp) if pol else None, **kw)

@@ -882,3 +882,22 @@ def test_dense_generator_problems_solve_against_oracle_literal(built, N, k0):
             xx = A @ xx + B @ uu + noise[b, t]
             xbar = xb[1]; e = xx - xbar
             np.testing.assert_allclose(sim["x"][b, t + 1], xx, atol=REL * (1 + np.abs(xx).max()))
+
+
+@pytest.mark.parametrize("case,Bn,T", [("pulley_n10", 48, 30), ("dim5_n20", 32, 24), ("di_n40", 32, 30), ("di_n10", 48, 30)])
+def test_calibrated_stopping_keeps_the_north_star_accuracy(built, case, Bn, T):
+    """The complementarity target is calibrated per problem (TZDDPC.mu_factor, tz_problem_set_stopping: loosest factor whose
+    simulated closed loop stays within 2e-8 of the tightest one).  Independent check on the example's TRUE plant and other noise:
+    states and inputs within the north-star 1e-6 of a much tighter, cold-started oracle solve of every step."""
+    from oracle.c_oracle import COracle
+    from tzddpc_amd.dist import vertex_noise
+    ctl, (A, B, zon) = common.gpu_controller(case)
+    assert ctl.mu_factor in (0.3, 0.1, 0.03, 0.01, 1e-3)
+    noise = vertex_noise(zon.W.compute_vertices(), 3, Bn, T)
+    x0 = np.tile(zon.X0.center, (Bn, 1))
+    sim = ctl.simulate_batch(x0, noise, A, B)
+    assert (sim["status"] == 0).all()
+    tight = COracle(ctl.qp, warm_floor=0.0, tol=1e-11, mu_factor=1e-3, res_factor=1.0, step_frac=0.99, max_iter=80).simulate_batch(x0, noise, A, B, threads=16)
+    assert (tight["status"] == 0).all()
+    np.testing.assert_allclose(sim["x"], tight["x"], atol=REL * (1 + np.abs(tight["x"]).max()))
+    np.testing.assert_allclose(sim["u"], tight["u"], atol=REL * (1 + np.abs(tight["u"]).max()))

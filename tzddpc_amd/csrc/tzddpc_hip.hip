@@ -1154,6 +1154,13 @@ int tz_problem_set_warm_shift(tz_problem* p, int32_t policy) {
   return TZ_OK;
 }
 
+int tz_problem_set_stopping(tz_problem* p, double res_factor, double mu_factor) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  if (!(res_factor >= 1.0) || !(mu_factor > 0.0) || !(mu_factor <= 1.0)) TZ_FAIL(TZ_ERR_INVALID, "need res_factor >= 1 and 0 < mu_factor <= 1");
+  p->res_factor = res_factor; p->mu_factor = mu_factor;
+  return TZ_OK;
+}
+
 int tz_problem_set_warm_quiet(tz_problem* p, int32_t quiet_steps) {
   if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
   if (quiet_steps < 0) TZ_FAIL(TZ_ERR_INVALID, "quiet_steps must be >= 0");

@@ -106,6 +106,8 @@ def lib():
     L.tz_problem_reset_warm.argtypes = [vp]
     L.tz_problem_attach_tube_stack.argtypes = [vp, vp]
     L.tz_problem_attach_tube_stack.restype = C.c_int
+    L.tz_problem_set_stopping.argtypes = [vp, C.c_double, C.c_double]
+    L.tz_problem_set_stopping.restype = C.c_int
     L.tz_problem_set_warm_quiet.argtypes = [vp, C.c_int32]
     L.tz_problem_set_warm_quiet.restype = C.c_int
     L.tz_problem_set_warm_push.argtypes = [vp, C.c_double, C.c_double]
@@ -129,7 +131,7 @@ def lib():
 EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy",
                     "tz_problem_set_stream", "tz_problem_sync", "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run",
                     "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch",
-                    "tz_problem_set_warm_shift", "tz_problem_set_warm_quiet", "tz_problem_set_warm_push", "tz_problem_reset_warm", "tz_identify_batch", "tz_specrad_batch", "tz_adversary_batch",
+                    "tz_problem_set_warm_shift", "tz_problem_set_stopping", "tz_problem_set_warm_quiet", "tz_problem_set_warm_push", "tz_problem_reset_warm", "tz_identify_batch", "tz_specrad_batch", "tz_adversary_batch",
                     "tz_problem_attach_tube_stack", "tz_genstack_create", "tz_genstack_destroy", "tz_genstack_intervals", "tz_genstack_values", "tz_genstack_info")
 
 
@@ -340,6 +342,9 @@ class Problem:
         """Literal problems: theta's tube block comes from the device evaluation of `stack` (``tz_problem_attach_tube_stack``)."""
         check(lib().tz_problem_attach_tube_stack(self._h, stack._h if stack is not None else None), "tz_problem_attach_tube_stack")
         self._tube_stack = stack                      # keeps it alive as long as the problem
+
+    def set_stopping(self, res_factor: float = 100.0, mu_factor: float = 1e-3):
+        check(lib().tz_problem_set_stopping(self._h, float(res_factor), float(mu_factor)), "tz_problem_set_stopping")
 
     def set_warm_quiet(self, quiet_steps: int = 16):
         check(lib().tz_problem_set_warm_quiet(self._h, int(quiet_steps)), "tz_problem_set_warm_quiet")
