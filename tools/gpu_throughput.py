@@ -7,6 +7,11 @@ from tzddpc_amd.dist import vertex_noise
 case = sys.argv[1]; Bn = int(sys.argv[2]); K = int(sys.argv[3]) if len(sys.argv) > 3 else 30; W = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 ctl, (A, B, zon) = common.gpu_controller(case)
 nat = ctl._native; n, m = ctl.qp.n, ctl.qp.m
+import os
+if os.environ.get("TZ_SHIFT_POLICY"):
+    ctl.warm_shift_policy = int(os.environ["TZ_SHIFT_POLICY"]); nat.set_warm_shift(ctl.warm_shift_policy)
+if os.environ.get("TZ_QUIET"):
+    nat.set_warm_quiet(int(os.environ["TZ_QUIET"]))
 dev = torch.device("cuda", 0)
 x = torch.from_numpy(np.tile(zon.X0.center, (Bn, 1))).to(dev); xbar = x.clone(); e = torch.zeros_like(x)
 noise = torch.from_numpy(np.ascontiguousarray(vertex_noise(zon.W.compute_vertices(), 0, Bn, K + W).transpose(1, 0, 2))).to(dev)
