@@ -187,6 +187,9 @@ static double max_step(int n, const double* v, const double* dv) {
   return a;
 }
 
+/* TZO_TRACE=1: per-iteration mu / residuals / step lengths on stderr (how the warm start of round 2 was found); read once */
+static int tzo_trace(void) { static int t = -1; if (t < 0) t = getenv("TZO_TRACE") != NULL; return t; }
+
 /* status: 0 solved, 1 max_iter, 2 numerical, 3 infeasible */
 /* warm != 0: x / lam hold the previous closed-loop step's solution of this trajectory; the slacks are re-derived for the
  * new h and (s, lam) pushed into the cone: sig = max(warm_floor, warm_gain * largest violation of the new rows), s >= sig,
@@ -241,7 +244,7 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
     for (int r = 0; r < mi; ++r) { rp[r] = gx[r] + s[r] - h[r]; nrp = fmax(nrp, fabs(rp[r])); mu += s[r] * lam[r]; }
     mu /= mi; nrd /= scd; nrp /= scp;
     *iters = it;
-    if (getenv("TZO_TRACE")) fprintf(stderr, "  it %d mu %.3e rd %.3e rp %.3e warm %d\n", it, mu, nrd, nrp, warm);
+    if (tzo_trace()) fprintf(stderr, "  it %d mu %.3e rd %.3e rp %.3e warm %d\n", it, mu, nrd, nrp, warm);
     if (nrd <= d->res_tol && nrp <= d->res_tol && mu <= d->mu_tol) return 0;
     if (mu <= 1e-3 * d->mu_tol && !(it == 0 && warm))       /* mu collapsed before the residuals: numerical (a warm start may BEGIN */
       return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 2;   /* there: its first Newton step is what removes the residuals) */
@@ -265,14 +268,14 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
       continue;
     }
     double sigma = muaff / mu; sigma = sigma * sigma * sigma;
-    if (getenv("TZO_TRACE")) fprintf(stderr, "     affine ap %.4f ad %.4f muaff/mu %.3e sigma %.3e\n", ap, ad, muaff / mu, sigma);
+    if (tzo_trace()) fprintf(stderr, "     affine ap %.4f ad %.4f muaff/mu %.3e sigma %.3e\n", ap, ad, muaff / mu, sigma);
     /* corrector */
     for (int r = 0; r < mi; ++r) { rc[r] = s[r] * lam[r] + ds[r] * dl[r] - sigma * mu; t1[r] = (-rc[r] + lam[r] * rp[r]) / s[r]; }
     for (int c = 0; c < nz; ++c) { double a = -rd[c]; for (int r = 0; r < mi; ++r) a -= S->G[r * nz + c] * t1[r]; dx[c] = a; }
     chol_solve(nz, H, dx);
     for (int r = 0; r < mi; ++r) { double a = 0; for (int c = 0; c < nz; ++c) a += S->G[r * nz + c] * dx[c]; gdx[r] = a; ds[r] = -rp[r] - a; dl[r] = (-rc[r] - lam[r] * ds[r]) / s[r]; }
     double alpha = fmin(1.0, d->step_frac * fmin(max_step(mi, s, ds), max_step(mi, lam, dl)));
-    if (getenv("TZO_TRACE")) fprintf(stderr, "     corrected step: ap %.4f ad %.4f\n", max_step(mi, s, ds), max_step(mi, lam, dl));
+    if (tzo_trace()) fprintf(stderr, "     corrected step: ap %.4f ad %.4f\n", max_step(mi, s, ds), max_step(mi, lam, dl));
     for (int c = 0; c < nz; ++c) x[c] += alpha * dx[c];
     for (int r = 0; r < mi; ++r) { s[r] += alpha * ds[r]; lam[r] += alpha * dl[r]; gx[r] += alpha * gdx[r]; }
   }
