@@ -104,7 +104,7 @@ def cpu_baseline(ctl, A, B, zon, label, warmup, steps, seconds_budget=25.0):
     from tzddpc_amd.builder import horizon_shift
     from tzddpc_amd.dist import vertex_noise
     pol = int(ctl.warm_shift_policy)       # same warm-start policy as the device chose at build time (the shift maps are data handed to the oracle)
-    co = COracle(ctl.qp, shift_policy=pol, shift_maps=horizon_shift(ctl.qp) if pol else None, warm_gain=float(getattr(ctl, "warm_push_gain", 1.0)), mu_factor=float(getattr(ctl, "mu_factor", 1e-3)))
+    co = COracle(ctl.qp, shift_policy=pol, shift_maps=horizon_shift(ctl.qp) if pol else None, warm_gain=float(getattr(ctl, "warm_push_gain", 1.0)), warm_cap=float(getattr(ctl, "warm_push_cap", 1e300)), mu_factor=float(getattr(ctl, "mu_factor", 1e-3)))
     host_cpus = os.cpu_count() or 1
     try:
         usable = len(os.sched_getaffinity(0))
@@ -294,7 +294,7 @@ def main():
                                    f"vertex-of-W noise PCG64(1000+i), all {K} timed steps in one launch",
                        "name": args.config, "trajectories_per_gpu": Bl, "horizon": horizon, "k0": k0, "nz": ctl.qp.nz, "rows": int(nat.mi),
                        "ipm_factorizations_per_trajectory_step": iters_mean, "warm_start": os.environ.get("TZ_WARM", "1") != "0",
-                       "warm_shift_policy": int(ctl.warm_shift_policy), "warm_push_gain": float(ctl.warm_push_gain), "mu_factor": float(ctl.mu_factor), "unsolved_trajectory_steps": int(nbad.item()),
+                       "warm_shift_policy": int(ctl.warm_shift_policy), "warm_push_gain": float(ctl.warm_push_gain), "warm_push_cap": (None if not np.isfinite(ctl.warm_push_cap) else float(ctl.warm_push_cap)), "mu_factor": float(ctl.mu_factor), "unsolved_trajectory_steps": int(nbad.item()),
                        "gathered_rows": int(gathered.shape[0]), "lds_bytes_per_workgroup": nat.plan_info()["lds_bytes"]},
             "timing": {"repeats": R, "reported": "median window", "window_ms": [round(w * 1e3, 4) for w in windows],
                        "window_ms_min": min(windows) * 1e3, "window_ms_max": max(windows) * 1e3,

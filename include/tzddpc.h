@@ -278,12 +278,14 @@ int tz_problem_set_warm_quiet(tz_problem* p, int32_t quiet_steps);
 int tz_problem_set_stopping(tz_problem* p, double res_factor, double mu_factor);
 
 /* Warm-started steps re-derive the slacks for the new right-hand side and push the point into the cone: with
- *     sigma = max(floor, gain * (largest violation of the new rows by the previous solution))      (scaled units)
+ *     sigma = min( max(floor, gain * (largest violation of the new rows by the previous solution)), cap )      (scaled units)
  * slack >= sigma and multiplier >= sigma^2 / slack (onto the central path of mu = sigma^2; inactive rows keep multipliers ~ 0).
- * The gain that costs the fewest interior-point iterations depends on the problem (measured on MI355X: the 5-dim example needs
- * 6.4 factorisations per step at gain 1 and 4.0 at 0.003, the pulley is best near 1, the double integrators do not care) -- the
- * Python layer calibrates it together with the shift policy.  Defaults: floor 1e-8, gain 1. */
-int tz_problem_set_warm_push(tz_problem* p, double floor, double gain);
+ * The rows are equilibrated, so a slack of order one is already far inside: violations of 5 ... 70 (the first steps of a
+ * transient, any step on a plant that differs from the model) would otherwise wipe out the slack information of the start; with
+ * the cap the best settings no longer depend on the plant (measured in the C oracle on the example's true plant and on the
+ * identified centre).  Gain and cap that cost the fewest interior-point iterations depend on the problem -- the Python layer
+ * calibrates them together with the shift policy.  Defaults: floor 1e-8, gain 1, no cap. */
+int tz_problem_set_warm_push(tz_problem* p, double floor, double gain, double cap);
 
 /* The closed-loop entry points (tz_mpc_step, tz_mpc_run) warm-start every trajectory from the solution the HANDLE holds for it from
  * the previous call with the same batch size.  Call this when the next call starts a new batch of trajectories (fresh x / xbar / e):

@@ -37,7 +37,7 @@ typedef struct tzo_desc {
   const double *CK, *DK, *K;      /* n x n, n x n, m x n */
   int32_t pmax; const double *absCK, *absKCK; const int32_t *power;
   int32_t max_iter; double tol, reg, step_frac;
-  double warm_floor, warm_gain;   /* closed-loop warm start (tzo_simulate_batch): see ipm() */
+  double warm_floor, warm_gain, warm_cap;   /* closed-loop warm start (tzo_simulate_batch): see ipm() */
   double mu_tol;                  /* complementarity target (<= tol) */
   double res_tol;                 /* residual tolerance of the stopping test (>= tol) */
   double aff_thr, aff_mu;         /* predictor step taken as the step when it is (nearly) full and leaves mu_aff <= aff_mu mu */
@@ -192,7 +192,7 @@ static int tzo_trace(void) { static int t = -1; if (t < 0) t = getenv("TZO_TRACE
 
 /* status: 0 solved, 1 max_iter, 2 numerical, 3 infeasible */
 /* warm != 0: x / lam hold the previous closed-loop step's solution of this trajectory; the slacks are re-derived for the
- * new h and (s, lam) pushed into the cone: sig = max(warm_floor, warm_gain * largest violation of the new rows), s >= sig,
+ * new h and (s, lam) pushed into the cone: sig = min(max(warm_floor, warm_gain * largest violation of the new rows), warm_cap), s >= sig,
  * lam >= sig^2 / s. */
 static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const double* h, double* x, double* s, double* lam, int* iters, double* wk, int warm) {
   /* warm == 2: as warm == 1 and gx (G x of the starting point) is still valid in the work area from the previous step;
@@ -213,7 +213,8 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
       if (warm != 2) { double a = 0; for (int c = 0; c < nz; ++c) a += S->G[r * nz + c] * x[c]; gx[r] = a; }
       viol = fmax(viol, gx[r] - h[r]);
     }
-    double sig = fmax(d->warm_floor, d->warm_gain * viol);
+    double sig = fmin(fmax(d->warm_floor, d->warm_gain * viol), d->warm_cap);
+    if (tzo_trace()) fprintf(stderr, "  warm: viol %.3e sig %.3e mode %d\n", viol, sig, warm);
     /* slack at least sig; multiplier at least sig^2 / s: the pair is pushed onto the central path of mu = sig^2 where it was
      * below it, and an inactive row (large slack, multiplier ~ 0) keeps a multiplier ~ 0 instead of being lifted to sig */
     for (int r = 0; r < mi; ++r) { s[r] = fmax(h[r] - gx[r], sig); lam[r] = fmax(lam[r], sig * sig / s[r]); }

@@ -24,7 +24,7 @@ class Desc(C.Structure):
                 ("f0", _dp), ("Ft", _dp), ("pl", _dp), ("pu", _dp), ("r0", C.c_double), ("r1", _dp), ("R2", _dp), ("Phi", _dp), ("Gam", _dp),
                 ("CK", _dp), ("DK", _dp), ("K", _dp), ("pmax", C.c_int32), ("absCK", _dp), ("absKCK", _dp), ("power", _ip),
                 ("max_iter", C.c_int32), ("tol", C.c_double), ("reg", C.c_double), ("step_frac", C.c_double),
-                ("warm_floor", C.c_double), ("warm_gain", C.c_double), ("mu_tol", C.c_double), ("res_tol", C.c_double), ("aff_thr", C.c_double), ("aff_mu", C.c_double),
+                ("warm_floor", C.c_double), ("warm_gain", C.c_double), ("warm_cap", C.c_double), ("mu_tol", C.c_double), ("res_tol", C.c_double), ("aff_thr", C.c_double), ("aff_mu", C.c_double),
                 ("shift_var", _ip), ("shift_row", _ip), ("shift_policy", C.c_int32), ("shift_quiet", C.c_int32)]
 
 
@@ -73,7 +73,7 @@ def lib():
 
 
 class COracle:
-    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999, warm_floor=1e-8, warm_gain=1.0, mu_factor=1e-3, res_factor=100.0, aff_thr=0.99, aff_mu=1e-3, shift_policy=0, shift_maps=None, shift_quiet=16):
+    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999, warm_floor=1e-8, warm_gain=1.0, warm_cap=1e300, mu_factor=1e-3, res_factor=100.0, aff_thr=0.99, aff_mu=1e-3, shift_policy=0, shift_maps=None, shift_quiet=16):
         self.qp = qp
         self._keep = []
         d = Desc()
@@ -95,6 +95,7 @@ class COracle:
         d.aff_thr, d.aff_mu = float(aff_thr), float(aff_mu)
         d.warm_floor, d.warm_gain = float(warm_floor), float(warm_gain)       # warm_floor = 0: every closed-loop step starts cold
         d.shift_quiet = int(shift_quiet)
+        d.warm_cap = float(min(warm_cap, 1e300))
         if shift_policy:                    # same receding-horizon shift of the warm start as the device (TZDDPC.warm_shift_policy):
             if shift_maps is None:          # the maps (source variable / source two-sided row) are handed in by the caller
                 raise ValueError("shift_policy != 0 needs shift_maps=(source variable of every variable, source row of every row)")

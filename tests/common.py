@@ -160,4 +160,5 @@ def c_oracle_for(ctl, **kw):
     pol = kw.pop("shift_policy", ctl.warm_shift_policy)
     kw.setdefault("warm_gain", float(getattr(ctl, "warm_push_gain", 1.0)))
     kw.setdefault("mu_factor", float(getattr(ctl, "mu_factor", 1e-3)))
+    kw.setdefault("warm_cap", float(getattr(ctl, "warm_push_cap", 1e300)))
     return COracle(ctl.qp, shift_policy=pol, shift_maps=horizon_shift(ctl.qp) if pol else None, **kw)

@@ -279,7 +279,7 @@ def test_single_wave_factor_path_equals_four_wave_path(built, monkeypatch):
         for k in ("TZ_CHOL1", "TZ_KSPLIT"):
             monkeypatch.delenv(k, raising=False)
         slow._native.set_warm_shift(fast.warm_shift_policy)      # same policy on both sides (the calibration is per build)
-        slow._native.set_warm_push(1e-8, fast.warm_push_gain)
+        slow._native.set_warm_push(1e-8, fast.warm_push_gain, fast.warm_push_cap)
         noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
         x0 = np.tile(zon.X0.center, (Bn, 1))
         a = fast.simulate_batch(x0, noise, A, B); b = slow.simulate_batch(x0, noise, A, B)
@@ -798,28 +798,29 @@ def test_solve_simplified2_segment_state_zonotope_is_infeasible(built):
 
 
 def test_warm_push_calibration_keeps_parity(built):
-    """The build-time calibration of the warm-start push (tz_problem_set_warm_push) only changes how many iterations a step needs:
-    the 5-dim closed loop is within the north-star tolerance of the C oracle for every candidate gain, and the calibrated gain
-    needs no more factorisations than the default."""
+    """The build-time calibration of the warm-start push (tz_problem_set_warm_push: gain and cap) only changes how many iterations a
+    step needs: the 5-dim closed loop is within the north-star tolerance of the C oracle for every setting, and the calibrated one
+    needs no more factorisations than the un-capped default."""
     from tzddpc_amd.dist import vertex_noise
     ctl, (A, B, zon) = common.gpu_controller("dim5_n20")
-    assert ctl.warm_push_gain in (1.0, 0.3, 0.1, 0.03, 0.01, 0.003, 0.001)
+    assert ctl.warm_push_gain in (1.0, 0.3, 0.1, 0.03) and (ctl.warm_push_cap in (0.3, 0.1, 0.03, 0.01) or not np.isfinite(ctl.warm_push_cap))
     Bn, T = 32, 16
     noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
     x0 = np.tile(zon.X0.center, (Bn, 1))
-    ref = common.c_oracle_for(ctl, warm_gain=1.0).simulate_batch(x0, noise, A, B, threads=16)
+    ref = common.c_oracle_for(ctl, warm_gain=1.0, warm_cap=1e300).simulate_batch(x0, noise, A, B, threads=16)
     work = {}
-    for g in (1.0, ctl.warm_push_gain, 0.003):
-        ctl._native.set_warm_push(1e-8, g)
+    chosen = (ctl.warm_push_gain, ctl.warm_push_cap)
+    for g, c in ((1.0, float("inf")), chosen, (1.0, 0.01), (0.03, float("inf"))):
+        ctl._native.set_warm_push(1e-8, g, c)
         ctl._native.timing_enable(True)
         run = ctl.simulate_batch(x0, noise, A, B)
-        work[g] = ctl._native.work_get()["factorizations"]
+        work[(g, c)] = ctl._native.work_get()["factorizations"]
         ctl._native.timing_enable(False)
         assert (run["status"] == 0).all()
         np.testing.assert_allclose(run["x"], ref["x"], atol=REL * (1 + np.abs(ref["x"]).max()))
         np.testing.assert_allclose(run["u"], ref["u"], atol=REL * (1 + np.abs(ref["u"]).max()))
-    ctl._native.set_warm_push(1e-8, ctl.warm_push_gain)
-    assert work[ctl.warm_push_gain] <= work[1.0]
+    ctl._native.set_warm_push(1e-8, *chosen)
+    assert work[chosen] <= work[(1.0, float("inf"))]
 
 
 @pytest.mark.parametrize("N,k0", [(3, None), (4, 1), (2, None)])

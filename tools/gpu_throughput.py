@@ -24,4 +24,4 @@ nat.timing_enable(True)
 t0 = time.perf_counter(); nat.mpc_run_ptr(Bn, K, *args(W)); nat.sync(); dt = time.perf_counter() - t0
 w = nat.work_get()
 print(f"{case}: nz={ctl.qp.nz} rows={nat.mi} B={Bn}: {Bn * K / dt:,.0f} MPC steps/s ({dt / K * 1e3:.3f} ms per step of the batch), "
-      f"{w['factorizations'] / max(w['trajectory_solves'], 1):.2f} factorisations per trajectory-step (warm-shift policy {ctl.warm_shift_policy}, push gain {ctl.warm_push_gain}), unsolved {int((st != 0).sum())} (+{bad0} in warm-up), plan {nat.plan_info()}")
+      f"{w['factorizations'] / max(w['trajectory_solves'], 1):.2f} factorisations per trajectory-step (warm-shift policy {ctl.warm_shift_policy}, push gain {ctl.warm_push_gain} cap {ctl.warm_push_cap}, mu {ctl.mu_factor}), unsolved {int((st != 0).sum())} (+{bad0} in warm-up), plan {nat.plan_info()}")

@@ -64,7 +64,7 @@ struct IpmParams {
   int chol1;                  // Tz <= 16: one wave factors H while the other three form the predictor's right-hand side
   int ksplit;                 // Gram by tz_form_H_ksplit (Tz <= TZ_KS_TZ) instead of the item plan
   int warm; double warm_floor;   // warm != 0: start from the x / lambda already stored for the trajectory (closed-loop steps)
-  double warm_gain;              // warm point pushed into the cone by max(warm_floor, warm_gain * violation of the new rows)
+  double warm_gain, warm_cap;    // warm point pushed into the cone by sigma = min(max(warm_floor, warm_gain * violation of the new rows), warm_cap)
   double aff_thr, aff_mu;        // predictor step taken as the step (no corrector solve) when it reaches aff_thr of the way to the
                                  // boundary un-damped and leaves mu_aff <= aff_mu * mu; aff_thr > 1 disables
   unsigned long long* work;   // [0] += factorisations, [1] += solved trajectories (bench.py roofline accounting); may be null
@@ -1143,7 +1143,7 @@ retry_solve:
     TZ_ROWS(k, r) { const double hv = TZ_H(k, r); viol = fmax(viol, TZ_GX(k, r) - hv); sch = fmax(sch, fabs(hv)); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
     tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red, rpar);      // also the scales of the stopping test
-    const double sig = fmax(pk.warm_floor, pk.warm_gain * viol);
+    const double sig = fmin(fmax(pk.warm_floor, pk.warm_gain * viol), pk.warm_cap);
     const double sig2 = sig * sig;
     TZ_ROWS(k, r) {                  // slack >= sig, multiplier >= sig^2 / slack: onto the central path of mu = sig^2 where the pair was
       s_[k] = fmax(TZ_H(k, r) - TZ_GX(k, r), sig);           // below it; an inactive row keeps its multiplier ~ 0 instead of being

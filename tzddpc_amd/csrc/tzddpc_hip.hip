@@ -180,7 +180,7 @@ struct tz_problem {
   int lastB = 0;
   bool prof = false;
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
-  double warm_floor = 1e-8, warm_gain = 1.0, mu_factor = 1e-3, res_factor = 100.0, aff_thr = 0.99, aff_mu = 1e-3;
+  double warm_floor = 1e-8, warm_gain = 1.0, warm_cap = 1e300, mu_factor = 1e-3, res_factor = 100.0, aff_thr = 0.99, aff_mu = 1e-3;
   bool warm_enabled = true;
   int ntube = 0;
   bool tt = false;             // tile-triangle layout / blocked Gram / two-phase Cholesky (nz > 64 or more than 1024 rows)
@@ -284,7 +284,7 @@ IpmParams ipm_params(tz_problem* p, int B, int* d_status, int* d_iters, bool war
   ip.shift_state = p->shift_state.p;
   ip.sx = p->shift_var.p; ip.sr = p->shift_row.p; ip.sxs = p->shift_xs.p; ip.sls = p->shift_ls.p;
   ip.warm = warm ? 1 : 0; ip.warm_floor = p->warm_floor;
-  ip.warm_gain = p->warm_gain; ip.aff_thr = p->aff_thr; ip.aff_mu = p->aff_mu;
+  ip.warm_gain = p->warm_gain; ip.warm_cap = p->warm_cap; ip.aff_thr = p->aff_thr; ip.aff_mu = p->aff_mu;
   ip.prev_status = warm ? p->prev_status.p : nullptr;
   ip.status_copy = track_prev ? p->prev_status.p : nullptr;
   ip.F.on = 0;
@@ -970,6 +970,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (const char* e = getenv("TZ_SHIFT_QUIET")) p->shift_quiet = atoi(e);
   if (const char* e = getenv("TZ_WARM_FLOOR")) { double v = atof(e); if (v > 0) p->warm_floor = v; }
   if (const char* e = getenv("TZ_WARM_GAIN")) p->warm_gain = atof(e);
+  if (const char* e = getenv("TZ_WARM_CAP")) { double v = atof(e); if (v > 0) p->warm_cap = v; }
   if (const char* e = getenv("TZ_MU_FACTOR")) p->mu_factor = atof(e);
   if (const char* e = getenv("TZ_RES_FACTOR")) p->res_factor = atof(e);
   if (const char* e = getenv("TZ_AFF_THR")) p->aff_thr = atof(e);
@@ -1168,10 +1169,10 @@ int tz_problem_set_warm_quiet(tz_problem* p, int32_t quiet_steps) {
   return TZ_OK;
 }
 
-int tz_problem_set_warm_push(tz_problem* p, double floor, double gain) {
+int tz_problem_set_warm_push(tz_problem* p, double floor, double gain, double cap) {
   if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
-  if (!(floor > 0.0) || !(gain >= 0.0)) TZ_FAIL(TZ_ERR_INVALID, "floor must be positive, gain non-negative");
-  p->warm_floor = floor; p->warm_gain = gain;
+  if (!(floor > 0.0) || !(gain >= 0.0) || !(cap >= floor)) TZ_FAIL(TZ_ERR_INVALID, "floor must be positive, gain non-negative, cap >= floor");
+  p->warm_floor = floor; p->warm_gain = gain; p->warm_cap = cap;
   return TZ_OK;
 }
 

@@ -110,7 +110,7 @@ def lib():
     L.tz_problem_set_stopping.restype = C.c_int
     L.tz_problem_set_warm_quiet.argtypes = [vp, C.c_int32]
     L.tz_problem_set_warm_quiet.restype = C.c_int
-    L.tz_problem_set_warm_push.argtypes = [vp, C.c_double, C.c_double]
+    L.tz_problem_set_warm_push.argtypes = [vp, C.c_double, C.c_double, C.c_double]
     L.tz_problem_set_warm_push.restype = C.c_int
     L.tz_problem_set_warm_shift.argtypes = [vp, C.c_int32]
     L.tz_timing_enable.argtypes = [vp, C.c_int]
@@ -349,8 +349,8 @@ class Problem:
     def set_warm_quiet(self, quiet_steps: int = 16):
         check(lib().tz_problem_set_warm_quiet(self._h, int(quiet_steps)), "tz_problem_set_warm_quiet")
 
-    def set_warm_push(self, floor: float = 1e-8, gain: float = 1.0):
-        check(lib().tz_problem_set_warm_push(self._h, float(floor), float(gain)), "tz_problem_set_warm_push")
+    def set_warm_push(self, floor: float = 1e-8, gain: float = 1.0, cap: float = 1e300):
+        check(lib().tz_problem_set_warm_push(self._h, float(floor), float(gain), float(min(cap, 1e300))), "tz_problem_set_warm_push")
 
     def set_warm_shift(self, policy: int):
         check(lib().tz_problem_set_warm_shift(self._h, int(policy)), "tz_problem_set_warm_shift")
