@@ -279,7 +279,8 @@ def main():
         # every trajectory-step also evaluates the stopping test of its starting point once more than it factorises (a warm start
         # that is already optimal costs exactly this and no factorisation): residual products P x, G'lambda, G x
         flop_per_test = nat.alg_flops["p_products"] + 0.5 * nat.alg_flops["g_products"]
-        flop_per_launch = nat.alg_flops["per_factorization"] * fact_per_launch + flop_per_test * solves[med]
+        flop_per_fixed = nat.alg_flops["per_step_fixed"]               # tube propagation (SURVEY 8d F_tube), affine maps, recovery, plant
+        flop_per_launch = nat.alg_flops["per_factorization"] * fact_per_launch + (flop_per_test + flop_per_fixed) * solves[med]
         avg_ms = float(np.median(kern_ms))
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
         sysname, _, _, _, k0, _, desc = CONFIGS[args.config]
@@ -306,12 +307,13 @@ def main():
                          "kernel": "tz_ipm_kernel", "avg_launch_ms": avg_ms, "launch_ms_all": [round(v, 5) for v in kern_ms], "launches": R,
                          "flop_per_launch": flop_per_launch,
                          "flop_per_factorization": nat.alg_flops["per_factorization"],
-                         "flop_per_stopping_test": flop_per_test, "factorizations_per_launch": fact_per_launch, "trajectory_steps_per_launch": solves[med],
+                         "flop_per_stopping_test": flop_per_test, "flop_per_step_fixed_part": flop_per_fixed, "factorizations_per_launch": fact_per_launch, "trajectory_steps_per_launch": solves[med],
                          "dense_flop_per_factorization": nat.alg_flops["dense_per_factorization"],
                          "note": "algorithmic f64 flops of one interior-point factorisation counted on the non-zeros of G (sparse outer products "
                                  "for G'WG, Cholesky, four G/G' products, two solve pairs, P x) x factorisations counted on the device, plus one "
                                  "stopping test (P x, G'lambda, G x) per trajectory-step -- a warm start that is already optimal costs only that; "
-                                 "the dense count is given beside it; tube / recovery / plant work of the fused step is not counted; launch time = "
+                                 "and the fixed part of a step (tube propagation F_tube of SURVEY 8d, the affine maps over theta, recovery, plant update); "
+                                 "the dense count of a factorisation is given beside it; launch time = "
                                  "median over the repeats of the HIP-event time of the one timed launch"},
         }
         tb, tinfo = archived_traffic(args.config, ctl.qp.nz, nat.mi, Bl, K)

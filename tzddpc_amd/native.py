@@ -273,6 +273,11 @@ class Problem:
                               g_products=8.0 * float(nnz_r.sum()), solves=8.0 * float(d.nz) ** 2,
                               p_products=2.0 * float((np.asarray(P) != 0).sum()))
         self.alg_flops["per_factorization"] = float(sum(self.alg_flops.values()))
+        # fixed part of one closed-loop step (F_tube = sum_k 2 n^2 (k n + n) + 2 m n (k n)), the three affine maps
+        # over theta, recovery of xbar[1] and the plant / error update
+        nmap = float(np.count_nonzero(Qt) + np.count_nonzero(Ht) + np.count_nonzero(Part))
+        f_tube = float(sum(2 * n * n * (k * n + n) + 2 * m * n * (k * n) for k in range(int(N))))
+        self.alg_flops["per_step_fixed"] = f_tube + 2.0 * nmap + 2.0 * n * (n + N * m) + 2.0 * n * (n + m) + 2.0 * m * n
         self.alg_flops["dense_per_factorization"] = float(d.mi * d.nz * (d.nz + 1) + d.nz ** 3 / 3.0 + 8.0 * d.mi * d.nz + 10.0 * d.nz ** 2)
         h = C.c_void_p()
         check(L.tz_problem_create(int(device), C.byref(d), C.byref(h)), "tz_problem_create")
