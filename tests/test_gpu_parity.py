@@ -902,3 +902,43 @@ def test_calibrated_stopping_keeps_the_north_star_accuracy(built, case, Bn, T):
     assert (tight["status"] == 0).all()
     np.testing.assert_allclose(sim["x"], tight["x"], atol=REL * (1 + np.abs(tight["x"]).max()))
     np.testing.assert_allclose(sim["u"], tight["u"], atol=REL * (1 + np.abs(tight["u"]).max()))
+
+
+def test_edge_shapes_against_oracle(built):
+    """Edge shapes of the batched entry points: horizon 1 (one input, the k = 0 tests are parameter-only), batches of 1, 3 and 1025
+    trajectories (not a multiple of anything), a single closed-loop step, zero noise; every result against the oracle."""
+    from tzddpc_amd import TZDDPC
+    from tzddpc_amd.dist import vertex_noise
+    from tzddpc_amd.harness import generate_trajectories, system
+    A, B, zon, T = system("di_cc")
+    rng = np.random.default_rng(25)
+    ctl = TZDDPC(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, rng))
+    ctl.build_zonotopes_theta(zon)
+    ctl.build_problem(1, common.loss_di, common.nocons)                  # horizon 1
+    x0, e0 = common.sample_params(zon, 2, 3)
+    out = ctl.solve_batch(x0, e0)
+    assert (out["status"] == 0).all() and out["v"].shape == (3, 1, 1) and out["xbar"].shape == (3, 2, 2)
+    for b in range(3):
+        o = common.oracle_solution(ctl.qp, x0[b], e0[b])
+        assert abs(out["cost"][b] - o["cost"]) <= 1e-7 * (1 + abs(o["cost"]))
+        np.testing.assert_allclose(out["xbar"][b, 1], o["xbar"][1], atol=REL * (1 + np.abs(o["xbar"]).max()))
+    res, v, xbar, ze1 = ctl.solve(x0[0], e0[0])
+    assert v.shape == (1, 1) and xbar.shape == (2, 2) and ze1.Z.value.shape[0] == 2
+    # ragged batch sizes on the benchmark problem
+    ctl2, (A, B, zon) = common.gpu_controller("di_n5")
+    co = common.c_oracle_for(ctl2)
+    for Bn, Tn in ((1, 7), (3, 1), (1025, 4)):
+        noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, Tn)
+        xs = np.tile(zon.X0.center, (Bn, 1))
+        sim = ctl2.simulate_batch(xs, noise, A, B)
+        ref = co.simulate_batch(xs, noise, A, B, threads=16)
+        assert sim["x"].shape == (Bn, Tn + 1, 2) and (sim["status"] == 0).all()
+        np.testing.assert_allclose(sim["x"], ref["x"], atol=REL * (1 + np.abs(ref["x"]).max()))
+        np.testing.assert_allclose(sim["u"], ref["u"], atol=REL * (1 + np.abs(ref["u"]).max()))
+    sim0 = ctl2.simulate_batch(np.tile(zon.X0.center, (2, 1)), np.zeros((2, 6, 2)), A, B)        # no noise
+    ref0 = co.simulate_batch(np.tile(zon.X0.center, (2, 1)), np.zeros((2, 6, 2)), A, B, threads=2)
+    np.testing.assert_allclose(sim0["x"], ref0["x"], atol=REL * (1 + np.abs(ref0["x"]).max()))
+    one = ctl2.solve_batch(zon.X0.center[None], np.zeros((1, 2)))
+    assert one["v"].shape == (1, 5, 1) and one["status"][0] == 0
+    with pytest.raises(Exception):
+        ctl2.solve_batch(np.zeros((2, 2)), np.zeros((3, 2)))              # mismatched batch sizes
