@@ -25,6 +25,13 @@ def loss_dim5(u, x):          # reference examples/3.5dimsystem_sim.py:14-20
     return cost
 
 
+def loss_dim5q(u, x):         # strictly convex loss on the 5-dim systems (oracle.harness.loss_dim5_quadratic): determines v with two inputs
+    cost = 0
+    for i in range(u.shape[0]):
+        cost += cp.norm(x[i, :] - np.array([0.0, 3.0, 0.0, 0.0, 0.0]), p=2) ** 2 + 1e-2 * cp.norm(u[i], p=1)
+    return cost
+
+
 def cons_dim5(u, x):          # reference examples/3.5dimsystem_sim.py:23-26
     return [x[:, 1] <= 10, x[:, 1] >= 2]
 
@@ -36,6 +43,10 @@ def nocons(u, x):
 def cons_di_eq(v, x):         # `==` rows (reference tzddpc/tzddpc.py:213-219 takes any DCP constraint): terminal state, move blocking
     return [x[x.shape[0] - 1, :] == np.array([-4.0, 0.0]), v[3] == v[4], v[5, 0] <= 0.9]
 
+
+# cases whose optimum is a face, not a point (the loss prices one state coordinate only and there are two inputs): parity on the
+# objective and the priced coordinate; input / state trajectories only against a solver on the SAME formulation (analytic centre)
+NONUNIQUE = {"dim5m2_n20"}
 
 CASES = {
     # name: (system, loss, constraints, horizon, k0)
@@ -51,15 +62,22 @@ CASES = {
     "di_n10_eq": ("di_cc", loss_di, cons_di_eq, 10, None),
     "pulley_n10": ("pulley", loss_pulley, nocons, 10, None),
     "dim5_n20": ("dim5_w001", loss_dim5, cons_dim5, 20, None),
+    # m = 2: the 5-dim system as BASELINE.json configs[3] states it (the loss's ||u_i||_2 is on the free variable of build_problem
+    # and vanishes, reference tzddpc/tzddpc.py:160,222), and a two-input double integrator
+    "dim5m2_n20": ("dim5m2_w001", loss_dim5, cons_dim5, 20, None),
+    "dim5m2q_n20": ("dim5m2_w001", loss_dim5q, cons_dim5, 20, None),
+    "di2in_n10": ("di2in", loss_di, nocons, 10, None),
+    "di2in_n10_k1": ("di2in", loss_di, nocons, 10, 1),
 }
 
 
-def identified_qp(case, seed=25, epigraph="auto"):
-    """Host-only: data -> Mdata -> collapsed parametric QP, without touching the GPU."""
+def identified_qp(case, seed=25, epigraph="auto", loss=None):
+    """Host-only: data -> Mdata -> collapsed parametric QP, without touching the GPU (`loss` replaces the case's callback)."""
     from tzddpc_amd import TZDDPC
     from tzddpc_amd.builder import build_parametric_qp
     from tzddpc_amd.harness import generate_trajectories, system
-    sysname, loss, cons, N, k0 = CASES[case]
+    sysname, loss_case, cons, N, k0 = CASES[case]
+    loss = loss or loss_case
     A, B, zon, T = system(sysname)
     rng = np.random.default_rng(seed)
     ctl = TZDDPC.__new__(TZDDPC)

@@ -34,6 +34,11 @@ CASES = {
     "di_n20_k2": ("di_cc", H.loss_di, None, 20, 2),
     "pulley_n10": ("pulley", H.loss_pulley, None, 10, None),
     "dim5_n20": ("dim5_w001", H.loss_dim5, H.constraints_dim5, 20, None),
+    # m = 2 (BASELINE.json configs[3] as stated: n = 5, m = 2; the reference example itself has one input) and a second two-input system
+    "dim5m2_n20": ("dim5m2_w001", H.loss_dim5, H.constraints_dim5, 20, None),
+    "dim5m2q_n20": ("dim5m2_w001", H.loss_dim5_quadratic, H.constraints_dim5, 20, None),     # strictly convex loss: v, xbar comparable
+    "di2in_n10": ("di2in", H.loss_di, None, 10, None),
+    "di2in_n10_k1": ("di2in", H.loss_di, None, 10, 1),
 }
 
 
@@ -98,8 +103,10 @@ def closed_loop(s, idn, N, k0, loss, cons, x0, noise):
     return xs, us, cost
 
 
-def main():
+def main(only=None):
     for case, (sysname, loss, cons, N, k0) in CASES.items():
+        if only and case not in only:
+            continue
         s, u, x, idn = identified(sysname)
         x0, e0 = sample_params(s, 4, **SAMPLING.get(case, {}))
         rec = dict(data_u=u, data_x=x, K=idn["K"], x0=x0, e0=e0)
@@ -109,6 +116,8 @@ def main():
         rec["provenance"] = np.array("oracle only: oracle.harness.identify + oracle.collapsed.build_collapsed + oracle.qp_ipm.solve_qp")
         np.savez_compressed(os.path.join(OUT, f"{case}.npz"), **rec)
         print(case, "cost", rec["cost"], "max cert", np.max(rec["cert"]))
+    if only:
+        return
     # G5: closed-loop double integrator (config-1 analogue: sim zonotopes, N = 2, 12 steps), fixed vertex noise
     s, u, x, idn = identified("di_sim")
     Wv = s["W"].compute_vertices()
@@ -118,7 +127,18 @@ def main():
     np.savez_compressed(os.path.join(OUT, "di_n2_closed_loop.npz"), data_u=u, data_x=x, K=idn["K"], x0=x0, noise=noise, x=xs, u=us, cost=cost,
                         provenance=np.array("oracle only"))
     print("closed loop final states", xs[:, -1])
+    # longer oracle-only closed loops, one of them with two inputs: (system, loss, constraints, N, k0, trajectories, steps)
+    for name, (sysname, loss, cons, N, k0, Bn, T) in {"di2in_n5_closed_loop": ("di2in", H.loss_di, None, 5, None, 2, 30),
+                                                       "pulley_n4_closed_loop": ("pulley", H.loss_pulley, None, 4, None, 2, 40)}.items():
+        s, u, x, idn = identified(sysname)
+        Wv = s["W"].compute_vertices()
+        noise = np.stack([Wv[np.random.Generator(np.random.PCG64(700 + i)).integers(len(Wv), size=T)] for i in range(Bn)])
+        x0 = np.tile(s["X0"].center, (Bn, 1))
+        xs, us, cost = closed_loop(s, idn, N, k0, loss, cons, x0, noise)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), data_u=u, data_x=x, K=idn["K"], x0=x0, noise=noise, x=xs, u=us, cost=cost,
+                            horizon=np.array(N), provenance=np.array("oracle only"))
+        print(name, "final states", xs[:, -1])
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

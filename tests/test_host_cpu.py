@@ -40,8 +40,16 @@ def test_cplite_atoms_and_values():
 
 def test_cplite_rejects_what_the_qp_path_cannot_express():
     u, x, nsym = _vars()
-    with pytest.raises(cp.CpliteError):
-        cp.as_convex(cp.norm(x[0, :], p=2), nsym)              # second-order cone
+    assert cp.as_convex(cp.norm(x[0, :], p=2), nsym).soc       # second-order cone: recorded; the builder drops it on a free u ...
+    with pytest.raises(cp.CpliteError):                        # ... and refuses it anywhere else
+        common.identified_qp("di_n5", loss=lambda u, x: cp.norm(x[1, :], p=2))
+    with pytest.raises(cp.CpliteError):                        # simplified problem: the loss sees v, not a free variable
+        common.identified_qp("di2in_n10_k1", loss=lambda u, x: cp.norm(u[0], p=2))
+    with pytest.raises(cp.CpliteError):                        # another term ties u down: the cone on u no longer vanishes
+        common.identified_qp("di2in_n10", loss=lambda u, x: cp.norm(u[0], p=2) + cp.norm(u[0] - 1.0, p=2) ** 2)
+    _, qp, _ = common.identified_qp("di2in_n10", loss=lambda u, x: common.loss_di(u, x) + cp.norm(u[0], p=2))
+    _, qp0, _ = common.identified_qp("di2in_n10")
+    assert qp.nz == qp0.nz and np.array_equal(qp.P, qp0.P) and np.array_equal(qp.q0, qp0.q0)      # vanished exactly
     with pytest.raises(cp.CpliteError):
         x[0, 0] * x[0, 1]
     with pytest.raises(cp.CpliteError):
@@ -216,3 +224,67 @@ def test_equality_elimination_preserves_the_optimum():
         np.testing.assert_allclose(qp.A[el.eq_rows] @ x, qp.u0[el.eq_rows] + qp.Ut[el.eq_rows] @ th, atol=1e-10)
     same, none = eliminate_equalities(common.identified_qp("di_n5")[1])
     assert none is None and same.nz == same.P.shape[0]
+
+
+def test_bench_gpus_flag_spawns_the_ranks_dry_run():
+    """`bench.py --gpus 2` outside torchrun starts two ranks itself (before anything touches a GPU) and relays rank 0's line; the
+    CPU rehearsal (--dry-run --backend gloo) exercises that launch + shard + gather logic: n_gpus 2, 2 x B gathered rows, the
+    world size read back from the process group, and the gathered table equal to the unsharded one."""
+    import json
+    root = common.__file__.rsplit("/tests/", 1)[0]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "33", "--dry-run",
+                        "--backend", "gloo"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                                   # ONE JSON line, from rank 0
+    ln = lines[0]
+    assert ln["n_gpus"] == 2 and ln["world_size_read_back"] == 2 and ln["config"]["gathered_rows"] == 66
+    assert ln["gather_matches_unsharded"] is True and len(ln["rank_window_ms"]) == 2
+    # under a launcher whose world size disagrees with --gpus the bench refuses instead of reporting a wrong n_gpus
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run", "--backend", "gloo"],
+                         env=dict(env, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+_SHARD_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from tests import common
+from tzddpc_amd.dist import shard_range, gather_results, vertex_noise
+from oracle.c_oracle import COracle
+rank = int(os.environ["RANK"]); ws = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=rank, world_size=ws)
+ctl, qp, (A, B, zon) = common.identified_qp("di_n5")
+total, T = 13, 6                                   # uneven shards: 7 + 6
+Wv = zon.W.compute_vertices()
+lo, hi = shard_range(total, ws, rank)
+co = COracle(qp)
+def loop(first, count):
+    out = co.simulate_batch(np.tile(zon.X0.center, (count, 1)), vertex_noise(Wv, first, count, T), A, B)
+    assert (out["status"] == 0).all()
+    return torch.from_numpy(np.concatenate([out["cost"].sum(axis=1)[:, None], out["x"][:, -1]], axis=1))
+got = gather_results(loop(lo, hi - lo), total)
+if rank == 0:
+    assert torch.equal(got, loop(0, total)), "sharded closed loops differ from the unsharded batch"
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_sharded_closed_loops_equal_the_unsharded_batch_gloo(built, tmp_path):
+    """The N > 1 data path end to end on CPU: two gloo ranks each run the closed loop of THEIR shard of trajectories (noise by
+    global trajectory index; the plain-C oracle stands in for the device, which this container does not have), one all-gather
+    of (cost, final state), and the table equals the unsharded run bit for bit -- trajectories are independent units."""
+    root = common.__file__.rsplit("/tests/", 1)[0]
+    script = tmp_path / "shard_worker.py"
+    script.write_text(_SHARD_WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script), root, port], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs

@@ -80,18 +80,24 @@ def test_product_builder_matches_oracle_collapsed(case):
         np.testing.assert_allclose(ref["xbar"][1], xb[1], atol=2e-6)
 
 
+@pytest.mark.parametrize("wc", [None, (3e-4, -2e-4)])
 @pytest.mark.parametrize("N,k0", [(3, None), (4, 1), (2, None)])
-def test_product_literal_problem_matches_oracle_literal_for_dense_generators(N, k0):
+def test_product_literal_problem_matches_oracle_literal_for_dense_generators(N, k0, wc):
     """Dense matrix-zonotope generators (Girard order 2): the product's literal problem (`build_parametric_qp(..., literal=stack)`,
     epigraph variables only for the decision-dependent generator entries, the rest numeric through theta) has the optimum of the
-    oracle's literal restatement (every generator entry an epigraph, reference tzddpc/tzddpc.py:172-207 / :283-324)."""
+    oracle's literal restatement (every generator entry an epigraph, reference tzddpc/tzddpc.py:172-207 / :283-324).
+    `wc`: a disturbance zonotope with a non-zero centre -- the constant part of the tube centres then is not zero and must enter
+    the rows exactly once (round-2 advisor finding: it was subtracted in the rows AND carried by theta)."""
     from oracle import harness as H, literal as OL
     from oracle.qp_ipm import solve_qp
+    from oracle.zonolite import Zonotope as OZ
     from tests import common
     from tzddpc_amd.builder import build_parametric_qp, theta_reference
     from tzddpc_amd.genstack import build_stack, count_generators
     from tzddpc_amd.zonotope import MatrixZonotope as PMZ, Zonotope as PZ
     s = H.system("di_cc"); rng = np.random.default_rng(25)
+    if wc is not None:
+        s = dict(s); s["W"] = OZ(np.asarray(wc), np.asarray(s["W"].generators))
     u, x = H.generate_trajectories(s["A"], s["B"], s["X0"], s["U"], s["W"], 1, s["T"], rng)
     idn = H.identify(u, x, s["W"])
     dK, dD = idn["MdataK_raw"].reduce(2), idn["Mdelta_raw"].reduce(2)

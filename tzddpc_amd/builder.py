@@ -249,7 +249,9 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
     if literal is not None:
         st = literal
         assert st.nseg >= N and st.n == n and st.m == m
-        cn[:] = st.c0[:N]; rx0[:] = 0.0; ru0[:] = 0.0; rxT[:] = 0.0; ruT[:] = 0.0
+        # the constant part c0 of the tube centres (W.center propagated) reaches the rows through theta's centre slot, which the
+        # device / theta_reference fill with c0 + C_K^p e0 from the e0-restricted stack: it must not be subtracted here as well
+        cn[:] = 0.0; rx0[:] = 0.0; ru0[:] = 0.0; rxT[:] = 0.0; ruT[:] = 0.0
         Mp_ = np.eye(n)
         pw_mats = [Mp_]
         for _ in range(pmax):
@@ -361,6 +363,11 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
             if _uses_u(e.C):
                 need_u = True
             terms[kind].append((w, e))
+    for w, e in loss.soc:
+        # ||F u||_2 of the FREE variable u (reference :160, :222: no constraint mentions it) is minimised to 0 independently of
+        # everything else -- exact as long as no other term ties u down; a cone on anything else has no QP form
+        if w != 0.0 and (need_u or not _only_u_homogeneous(e)):
+            raise CpliteError(cplite.SOC_MESSAGE)
     u_var0 = None
     if need_u:
         u_var0 = nzc; nzc += N * m
@@ -614,6 +621,8 @@ def build_simplified2_qp(Acl, Bhat, K, deltaA, deltaB, W_c, W_G, Zsigma, Xz, Uz,
     if loss is None:
         raise Exception("Loss function is not defined or is not convex!")
     loss = cplite.as_convex(loss, nsym)
+    if any(w != 0.0 for w, _ in loss.soc):
+        raise CpliteError(cplite.SOC_MESSAGE)
     cons = build_constraints(ubar_expr, xbar_expr[1:]) if build_constraints is not None else []
     cons = [] if cons is None else list(cons)
     for idx, c in enumerate(cons):

@@ -13,8 +13,11 @@ examples use, ``examples/1.double_integrator_sim.py:22-34``, ``examples/2.pulley
   ``norm(e, 'inf')``, ``norm(scalar, 2)`` (== abs), ``sum``, comparisons ``<= >= ==`` between
   affine expressions and constants.
 
-Anything else (``norm(vector, 2)`` un-squared, i.e. a second-order cone, products of
-expressions, non-convex use) raises ``CpliteError`` at build time -- never a silent fallback.
+``norm(vector, 2)`` un-squared (a second-order cone) is *recorded* (``Convex.soc``) and the builder decides: on the free
+variable ``u`` of ``build_problem`` (reference ``tzddpc/tzddpc.py:160, 222``: constrained by nothing) its minimum is 0 and the
+term drops out exactly -- ``1e-1 * cp.norm(u[i], p=2)`` of ``examples/3.5dimsystem_sim.py:19`` with ``dim_u > 1`` --; anywhere
+else it raises ``CpliteError``.  Anything else (products of expressions, non-convex use) raises ``CpliteError`` at build time
+-- never a silent fallback.
 
 Use in an example:  ``from tzddpc_amd import cplite as cp``  instead of ``import cvxpy as cp``.
 """
@@ -229,6 +232,7 @@ class Convex:
         self.sq: list = []      # (w, Affine vector)
         self.ab: list = []      # (w, Affine vector)  -> w * sum |.|
         self.mx: list = []      # (w, Affine vector)  -> w * max |.|
+        self.soc: list = []     # (w, Affine vector)  -> w * ||.||_2 : only the builder knows whether it can be honoured
 
     shape = ()
 
@@ -238,14 +242,14 @@ class Convex:
     def copy(self):
         c = Convex(self.nsym)
         c.const = self.const; c.lin = self.lin.copy()
-        c.sq = list(self.sq); c.ab = list(self.ab); c.mx = list(self.mx)
+        c.sq = list(self.sq); c.ab = list(self.ab); c.mx = list(self.mx); c.soc = list(self.soc)
         return c
 
     def __add__(self, other):
         out = self.copy()
         if isinstance(other, Convex):
             out.const += other.const; out.lin += other.lin
-            out.sq += other.sq; out.ab += other.ab; out.mx += other.mx
+            out.sq += other.sq; out.ab += other.ab; out.mx += other.mx; out.soc += other.soc
         elif isinstance(other, Affine):
             if other.size != 1:
                 raise CpliteError("loss must be scalar")
@@ -267,6 +271,7 @@ class Convex:
         out.sq = [(a * w, e) for a, e in self.sq]
         out.ab = [(a * w, e) for a, e in self.ab]
         out.mx = [(a * w, e) for a, e in self.mx]
+        out.soc = [(a * w, e) for a, e in self.soc]
         return out
 
     __rmul__ = __mul__
@@ -285,11 +290,18 @@ class Convex:
             v += w * float(np.sum(np.abs(e.value_at(xi))))
         for w, e in self.mx:
             v += w * float(np.max(np.abs(e.value_at(xi))))
+        for w, e in self.soc:
+            v += w * float(np.sqrt(np.sum(e.value_at(xi) ** 2)))
         return v
 
 
+SOC_MESSAGE = ("norm(vector, 2) (a second-order cone) is not supported by the QP path except on the free input variable of "
+               "build_problem, where it vanishes; use norm(., 2)**2, norm(., 1) or norm(., 'inf')")
+
+
 class _Norm2(Convex):
-    """``norm(e, 2)``: only usable squared, or directly when ``e`` is a scalar (== abs)."""
+    """``norm(e, 2)``: squared it is a quadratic, of a scalar it is ``abs``; of a vector it is a second-order cone, recorded in
+    ``soc`` for the builder to drop (free ``u``) or refuse (``SOC_MESSAGE``)."""
 
     def __init__(self, e: Affine):
         super().__init__(e.nsym)
@@ -297,12 +309,7 @@ class _Norm2(Convex):
         if self._e.size == 1:
             self.ab = [(1.0, self._e)]
         else:
-            self._soc = True
-
-    def _check(self):
-        if getattr(self, "_soc", False):
-            raise CpliteError("norm(vector, 2) (a second-order cone) is not supported by the QP path; "
-                              "use norm(., 2)**2, norm(., 1) or norm(., 'inf')")
+            self.soc = [(1.0, self._e)]
 
     def __pow__(self, p):
         if p != 2:
@@ -310,19 +317,6 @@ class _Norm2(Convex):
         out = Convex(self.nsym)
         out.sq = [(1.0, self._e)]
         return out
-
-    def __add__(self, other):
-        self._check(); return Convex.__add__(self, other)
-
-    __radd__ = __add__
-
-    def __mul__(self, w):
-        self._check(); return Convex.__mul__(self, w)
-
-    __rmul__ = __mul__
-
-    def copy(self):
-        self._check(); return Convex.copy(self)
 
 
 def _aff(e, like=None):
@@ -401,9 +395,6 @@ def hstack(parts: Sequence[Affine]):
 
 def as_convex(e, nsym) -> Convex:
     """Normalise whatever a loss callback returned into a ``Convex``."""
-    if isinstance(e, _Norm2):
-        e._check()
-        return e
     if isinstance(e, Convex):
         return e
     if isinstance(e, Affine):

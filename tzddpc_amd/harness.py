@@ -41,7 +41,8 @@ def generate_trajectories(*args, rng: Optional[np.random.Generator] = None) -> D
         X[j, 0] = X0.sample(1, rng)[0]
         for i in range(1, num_steps):
             pick = np.random.choice(len(Wv)) if rng is None else rng.integers(len(Wv))
-            X[j, i] = A @ X[j, i - 1] + np.squeeze(B * u[j, i - 1]) + Wv[pick]
+            # reference :40: np.squeeze(B * u) -- B @ u for dim_u = 1, a shape error for dim_u > 1 (no reference example has one)
+            X[j, i] = A @ X[j, i - 1] + B @ u[j, i - 1] + Wv[pick]
             Y[j, i] = X[j, i]
     return Data(u.reshape(total, m), Y.reshape(total, n))
 
@@ -64,12 +65,21 @@ def system(name: str):
         n, m = B.shape
         return A, B, SystemZonotopes(Zonotope([0] * n, np.zeros((n, 1))), Zonotope([1] * m, 3 * np.ones((m, 1))),
                                      Zonotope([1] * n, 2 * np.ones((n, 1))), Zonotope([0] * n, 0.1 * np.ones((n, 1)))), 400
-    if name in ("dim5", "dim5_w001"):
+    if name in ("dim5", "dim5_w001", "dim5m2", "dim5m2_w001"):
+        # '...m2': BASELINE.json configs[3] as stated (n = 5, m = 2) -- SURVEY.md 8d's synthetic second input column (1,0,1,0,1)';
+        # U = <[7] * dim_u, 100 I> is the example's own formula (examples/3.5dimsystem_sim.py:44)
         Ac = np.array([[-1, -4, 0, 0, 0], [4, -1, 0, 0, 0], [0, 0, -3, 1, 0], [0, 0, -1, -3, 0], [0, 0, 0, 0, -2.0]])
-        Bc = np.ones((5, 1))
+        Bc = np.ones((5, 1)) if "m2" not in name else np.array([[1.0, 1.0], [1.0, 0.0], [1.0, 1.0], [1.0, 0.0], [1.0, 1.0]])
+        m = Bc.shape[1]
         A, B, _, _, _ = scipysig.cont2discrete((Ac, Bc, np.eye(5), 0 * Bc), dt=0.05)
         Id = 20 * np.ones((5, 1)); Id[1] = 19
-        w = 0.01 if name == "dim5_w001" else 0.1
-        return A, B, SystemZonotopes(Zonotope([-2, 4, 3, -2.5, 5.5], np.zeros((5, 5))), Zonotope([7], 100 * np.eye(1)),
+        w = 0.01 if name.endswith("_w001") else 0.1
+        return A, B, SystemZonotopes(Zonotope([-2, 4, 3, -2.5, 5.5], np.zeros((5, 5))), Zonotope([7] * m, 100 * np.eye(m)),
                                      Zonotope([1, 20, 1, 1, 1], Id), Zonotope([0] * 5, w * np.ones((5, 1)))), 400
+    if name == "di2in":
+        # two-input double integrator (no counterpart in the reference; second m >= 2 system of the parity suite)
+        A = np.array([[1.0, 1.0], [0.0, 1.0]]); B = np.array([[0.5, 0.4], [1.0, 0.0]])
+        return A, B, SystemZonotopes(Zonotope([-5, -2], 0 * np.eye(2)), Zonotope([0, 0], np.diag([1.0, 0.5])),
+                                     Zonotope([-4, 0], 1.2 * np.diag([5, 2.5])),
+                                     Zonotope(np.zeros(2), 0.001 * np.array([[1, 0.5], [0.5, 1]]))), 100
     raise KeyError(name)

@@ -255,8 +255,12 @@ class TZDDPC(object):
         self.qp = qp
         self.horizon = int(horizon)
         self.k0 = k0
-        warm_shift = solver_kwargs.pop("warm_shift", "auto")
-        warm_gain = solver_kwargs.pop("warm_gain", "auto")
+        # calibrate=False: no build-time closed loops on the device -- warm start never shifted, push gain 1 without a cap, the
+        # tight complementarity target 1e-3 tol (each of the three can still be given explicitly)
+        calibrate = bool(solver_kwargs.pop("calibrate", True))
+        warm_shift = solver_kwargs.pop("warm_shift", "auto" if calibrate else "off")
+        warm_gain = solver_kwargs.pop("warm_gain", "auto" if calibrate else (1.0, float("inf")))
+        mu_factor = solver_kwargs.pop("mu_factor", "auto" if calibrate else 1e-3)
         self._drop_native()
         self._native, info = self._native_from_qp(qp, solver_kwargs)
         self._elim, self._scal, self._row_of = info["elim"], info["scal"], info["row_of"]
@@ -267,9 +271,13 @@ class TZDDPC(object):
         # larger than a real plant's and turned the preference around on the double integrators)
         # the two warm-start knobs are calibrated at the tightest complementarity target, then the target is relaxed as far as
         # the closed loop allows
+        import time
+        t0 = time.perf_counter()
         self.warm_shift_policy = self._choose_warm_shift(warm_shift, A, B)
         self.warm_push_gain, self.warm_push_cap = self._choose_warm_push(warm_gain, A, B)
-        self.mu_factor = self._choose_mu_factor(solver_kwargs.pop("mu_factor", "auto"), A, B)
+        self.mu_factor = self._choose_mu_factor(mu_factor, A, B)
+        self.calibration_seconds = time.perf_counter() - t0       # ~31 closed loops of 24 x 48 steps when everything is "auto"
+        self.calibrated = dict(warm_shift=warm_shift == "auto", warm_push=warm_gain == "auto", mu_factor=mu_factor == "auto")
         self.problem_full = self._native
         self.optimization_problem = self._native
         return self._native
@@ -321,6 +329,18 @@ class TZDDPC(object):
             absCKpow=qp.tube.absCKpow, absKCKpow=qp.tube.absKCKpow, power=qp.tube.power, **shift, **opts)
         return nat, dict(elim=elim, scal=(D, E, c), row_of=row_of, qp=qp)
 
+    def _calibration_noise(self, Bn, T):
+        """Disturbances of the build-time calibration loops: uniformly random vertices of W (what the examples' plants draw,
+        ``examples/1.double_integrator_sim.py:85``); with many generators the 2^g candidate vertices are not enumerated but
+        sampled directly as c + G s, s in {-1, 1}^g."""
+        W = self.zonotopes.W
+        rng = np.random.default_rng(12345)
+        if W.num_generators <= 12:
+            Wv = W.compute_vertices()
+            return Wv[rng.integers(0, Wv.shape[0], size=(Bn, T))]
+        sg = rng.integers(0, 2, size=(Bn, T, W.num_generators)) * 2.0 - 1.0
+        return np.asarray(W.center, float)[None, None] + sg @ np.asarray(W.generators, float).T
+
     def _choose_warm_shift(self, mode, A_model, B_model) -> int:
         """Warm-start policy of the closed-loop entry points (``tz_problem_set_warm_shift``): ``"off"`` / 0, ``"on"`` / 1, an
         integer k >= 2 (shift after steps of >= k iterations) or ``"auto"``: a 48-step closed loop of the identified model from
@@ -336,10 +356,8 @@ class TZDDPC(object):
             policy = int(mode)
         elif mode == "auto":
             zon = self.zonotopes
-            Wv = zon.W.compute_vertices()
             Bn, T = 24, 48            # long enough to see the steady state as well: a shift can help the transient and hurt afterwards
-            rng = np.random.default_rng(12345)
-            noise = Wv[rng.integers(0, Wv.shape[0], size=(Bn, T))]
+            noise = self._calibration_noise(Bn, T)
             x0 = np.tile(np.asarray(zon.X0.center, float), (Bn, 1))
             best, policy = None, 0
             for cand in (0, 3):       # "always" (1) is not a candidate: whether it beats 3 turned out to depend on the model mismatch
@@ -367,10 +385,8 @@ class TZDDPC(object):
             mu = float(mode)
         else:
             zon = self.zonotopes
-            Wv = zon.W.compute_vertices()
             Bn, T = 24, 48
-            rng = np.random.default_rng(12345)
-            noise = Wv[rng.integers(0, Wv.shape[0], size=(Bn, T))]
+            noise = self._calibration_noise(Bn, T)
             x0 = np.tile(np.asarray(zon.X0.center, float), (Bn, 1))
             nat.set_stopping(100.0, 1e-3)
             xr, ur, _, sr = nat.simulate_batch(x0, noise, A_model, B_model)
@@ -402,10 +418,8 @@ class TZDDPC(object):
             gain, cap = (float(mode[0]), float(mode[1])) if isinstance(mode, (tuple, list)) else (float(mode), float("inf"))
         else:
             zon = self.zonotopes
-            Wv = zon.W.compute_vertices()
             Bn, T = 24, 48
-            rng = np.random.default_rng(12345)
-            noise = Wv[rng.integers(0, Wv.shape[0], size=(Bn, T))]
+            noise = self._calibration_noise(Bn, T)
             x0 = np.tile(np.asarray(zon.X0.center, float), (Bn, 1))
             inf = float("inf")
             cands = [(1.0, inf), (0.3, inf), (0.1, inf), (0.03, inf)] + [(g, c) for c in (0.3, 0.1, 0.03, 0.01) for g in (1.0, 0.1)]
@@ -449,12 +463,15 @@ class TZDDPC(object):
         return float(cost[0]), v[0], xbar[0], self._ze1(np.asarray(xbar0, float).reshape(-1), np.asarray(e0, float).reshape(-1), v[0][0])
 
     def _simplified2_problem(self, horizon, Zsigma, build_loss, build_constraints, solver_kwargs):
-        """Device problem of ``solve_simplified2`` for (horizon, Zsigma, callbacks); the reference rebuilds its cvxpy problem on
-        every call (``:406-486``), here it is kept until one of them changes."""
+        """Device problem of ``solve_simplified2`` for (horizon, Zsigma, callbacks, solver options); the reference rebuilds its cvxpy
+        problem on every call (``:406-486``), here it is kept until one of them changes.  The callbacks are compared by identity:
+        pass the same function objects on every call (a fresh lambda per call rebuilds the problem -- QR elimination and
+        ``tz_problem_create`` -- at every MPC step)."""
         from .builder import build_simplified2_qp
         ze_sum = str(solver_kwargs.pop("ze_sum", "radius"))
         zs = [(np.asarray(Z.center, float), np.asarray(Z.generators, float)) for Z in Zsigma]
-        key = (int(horizon), build_loss, build_constraints, ze_sum, tuple(c.tobytes() + g.tobytes() for c, g in zs),
+        consumed = tuple((k, solver_kwargs.get(k)) for k in ("max_iter", "tol", "reg", "step_frac"))      # read by _native_from_qp below
+        key = (int(horizon), build_loss, build_constraints, ze_sum, consumed, tuple(c.tobytes() + g.tobytes() for c, g in zs),
                np.asarray(self.theta.K).tobytes(), np.asarray(self.theta.deltaA).tobytes(), np.asarray(self.theta.deltaB).tobytes())
         cur = getattr(self, "_s2", None)
         if cur is not None and cur["key"] == key:
