@@ -119,7 +119,7 @@ def cpu_baseline(ctl, A, B, zon, label, warmup, steps, seconds_budget=24.0, repe
     """Plain-C oracle (oracle/c/tz_oracle.c: the same algorithm incl. the closed-loop warm start, own scaling / Cholesky) on ALL host
     cores: the same closed-loop workload on a bounded number of trajectories; the `warmup` leading steps are timed separately and
     subtracted, so the rate covers the same steps as the GPU number.  `repeats` timed samples (median and spread reported); one
-    thread timed on a sample of at least a second.  OMP_PROC_BIND / OMP_PLACES are set by main() before the OpenMP runtime loads."""
+    thread timed on a sample of at least a second.  OMP_PROC_BIND / OMP_PLACES: as the caller set them, reported."""
     from oracle.c_oracle import COracle
     from tzddpc_amd.builder import horizon_shift
     from tzddpc_amd.dist import vertex_noise
@@ -379,9 +379,8 @@ def main(argv=None):
     if in_torchrun and world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
         return 2
-    # the CPU baseline's OpenMP runtime reads these when it is loaded
-    os.environ.setdefault("OMP_PROC_BIND", "spread")
-    os.environ.setdefault("OMP_PLACES", "cores")
+    # OMP_PROC_BIND / OMP_PLACES are left as the caller set them (reported in cpu_baseline.omp): on the GPU box OMP_PLACES=cores cut the
+    # OpenMP team of the baseline to 2 threads of the 128 the container may use
     if args.dry_run:
         return dry_run(args)
 

@@ -40,11 +40,14 @@ typedef enum tz_status {
 enum {
   TZ_SOLVED = 0,
   TZ_MAX_ITER = 1,          /* iteration cap hit before the tolerances                              */
-  TZ_NUMERICAL = 2,         /* non-finite iterate / failed factorisation                            */
-  TZ_INFEASIBLE = 3,        /* complementarity exhausted with residual left, or a parameter-only    */
-                            /* constraint violated (e.g. xbar0 + e0 outside X, reference            */
-                            /* tzddpc/tzddpc.py:191-195 at k = 0); the reference raises              */
-                            /* Exception('Problem is unbounded') for both (tzddpc/tzddpc.py:374-375) */
+  TZ_NUMERICAL = 2,         /* non-finite iterate, a factorisation that fails even with the largest */
+                            /* diagonal shift, or complementarity collapsed before the residuals    */
+  TZ_INFEASIBLE = 3,        /* a parameter-only constraint is violated (e.g. xbar0 + e0 outside X,  */
+                            /* reference tzddpc/tzddpc.py:191-195 at k = 0), or a failed solve       */
+                            /* whose multipliers are a Farkas certificate of primal infeasibility   */
+                            /* (y = lam / max lam >= 0, |G'y| <= 1e-6, h'y < -1e-6); the reference   */
+                            /* raises Exception('Problem is unbounded') for an infeasible problem    */
+                            /* (tzddpc/tzddpc.py:374-375)                                            */
 };
 
 enum { TZ_MEM_HOST = 0, TZ_MEM_DEVICE = 1 };

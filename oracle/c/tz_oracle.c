@@ -194,7 +194,7 @@ static int tzo_trace(void) { static int t = -1; if (t < 0) t = getenv("TZO_TRACE
 /* warm != 0: x / lam hold the previous closed-loop step's solution of this trajectory; the slacks are re-derived for the
  * new h and (s, lam) pushed into the cone: sig = min(max(warm_floor, warm_gain * largest violation of the new rows), warm_cap), s >= sig,
  * lam >= sig^2 / s. */
-static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const double* h, double* x, double* s, double* lam, int* iters, double* wk, int warm) {
+static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const double* h, double* x, double* s, double* lam, int* iters, double* wk, int warm, double regx0) {
   /* warm == 2: as warm == 1 and gx (G x of the starting point) is still valid in the work area from the previous step;
    * warm == 3: the previous (x, lambda) moved one step along the horizon first (values move unscaled, hence the D / E ratios) */
   int nz = S->nz, mi = S->mi;
@@ -234,6 +234,7 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
   for (int r = 0; r < mi; ++r) scp = fmax(scp, fabs(h[r]));
   scd += 1.0; scp += 1.0;
   int it;
+  double regx = regx0;               /* diagonal shift of the Newton matrix: 0, raised when a factorisation breaks down; the retry starts at 1e-6 */
   for (it = 0; it < d->max_iter; ++it) {
     double nrd = 0, nrp = 0, mu = 0;
     for (int c = 0; c < nz; ++c) {
@@ -251,8 +252,17 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
       return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 2;   /* there: its first Newton step is what removes the residuals) */
     if (!(mu == mu) || !(nrd == nrd) || mu > 1e200) return 2;
     for (int r = 0; r < mi; ++r) w[r] = lam[r] / s[r];
-    form_H(S, w, d->reg, H, GW);
-    if (!cholesky(nz, H)) return 2;
+    /* Newton matrix; a factorisation that breaks down (degenerate problems late in the solve: the weights of active and inactive
+     * rows are 1e18 apart and H loses definiteness in rounding) raises the diagonal shift, 1e-9, 1e-6, 1e-3, 1 -- kept for the rest
+     * of the solve -- and the iteration is repeated from the same point (it counts as an iteration, as on the device).  A shifted H
+     * only damps the Newton step (proximal term); the residuals are always exact. */
+    form_H(S, w, d->reg + regx, H, GW);
+    if (!cholesky(nz, H)) {
+      if (regx >= 1.0 || (regx0 == 0.0 && getenv("TZO_NO_ESCALATE"))) return 2;     /* the switch: test of the retry path alone */
+      regx = regx == 0.0 ? 1e-9 : regx * 1e3;
+      if (tzo_trace()) fprintf(stderr, "     factorisation failed: diagonal shift %.1e\n", regx);
+      continue;
+    }
     /* predictor */
     for (int r = 0; r < mi; ++r) t1[r] = w[r] * rp[r] - lam[r];
     for (int c = 0; c < nz; ++c) { double a = -rd[c]; for (int r = 0; r < mi; ++r) a -= S->G[r * nz + c] * t1[r]; dx[c] = a; }
@@ -323,11 +333,12 @@ static void solve_one(const tzo_desc* d, const setup_t* S, const double* xbar0, 
       for (int t = 0; t < nt; ++t) a += M[r * nt + t] * th[t];
       h[k] = S->E[k] * S->sgn[k] * a;
     }
-    st = ipm(d, S, q, h, x, s, lam, &it, iw, warm);
+    st = ipm(d, S, q, h, x, s, lam, &it, iw, warm, 0.0);
     if (st != 0) {                      /* same safeguard as the device kernel: once more, cold, textbook fraction to the boundary */
       tzo_desc d2 = *d; int it2 = 0;
       d2.step_frac = fmin(d->step_frac, 0.99);
-      st = ipm(&d2, S, q, h, x, s, lam, &it2, iw, 0);
+      st = ipm(&d2, S, q, h, x, s, lam, &it2, iw, 0, 1e-6);      /* ... and a shifted Newton matrix from the first iteration (a breakdown the
+                                                                   * pivot test did not see: tiny positive pivots, garbage step) */
       it += it2;
       if (st != 0 && farkas(S, h, lam)) st = 3;
     }

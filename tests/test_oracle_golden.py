@@ -112,8 +112,10 @@ def reference_pulley_envelope_checks(x, g, label):
     trajectory comparison: it is the only link to numbers the reference itself produced."""
     assert x.shape[1:] == (201, 4) and tuple(g["shape"][1:]) == (201, 4)
     np.testing.assert_array_equal(x[:, 0], 0.0)
-    first = x[:, 1, 0]                           # reference: 0.916 ... 1.101 (= 1 + w, |w| <= 0.1): the target is reached in ONE step
-    assert first.min() >= 0.90 - 1e-6 and first.max() <= 1.10 + 1e-6, (label, first.min(), first.max())
+    # reference: 0.916 ... 1.101: the nominal state reaches the target in ONE step, the plant lands at 1 + w + (model mismatch of
+    # the identified B times v0, a few 1e-3), |w| <= 0.1
+    first = x[:, 1, 0]
+    assert first.min() >= 0.90 - 5e-3 and first.max() <= 1.10 + 5e-3, (label, first.min(), first.max())
     assert abs(first.mean() - 1.0) <= 0.005 + 4 * 0.0578 / np.sqrt(x.shape[0]), (label, first.mean())        # 4 sigma of the mean of B draws of 0.1 U(-1, 1)
     assert g["first_step"][:, 0].min() >= 0.90 and g["first_step"][:, 0].max() <= 1.11          # ... in the reference's runs as well
     tail = x[:, -50:]
@@ -122,9 +124,16 @@ def reference_pulley_envelope_checks(x, g, label):
     assert abs(tail[:, :, 0].mean() - 1.0) <= 0.01, (label, tail[:, :, 0].mean())
     ds = np.abs(tail.std(axis=(0, 1)) - g["tail_std"])
     assert np.all(ds <= 0.01 + 0.1 * g["tail_std"]), (label, ds)                               # 0.058 = std of 0.1 U(-1, 1) on state 0
-    lo, hi = g["state_min"] - 0.05, g["state_max"] + 0.05
+    # global envelope.  The plant is a shift register (companion form of examples/2.pulley_sim.py:39-43) driven by ONE noise generator
+    # 0.1 * ones(4): state k is state 0 delayed by k steps plus k further noise draws, so once state 0 tracks 1 + w its support is
+    # [-0.1 k, 1 + 0.1 (k + 1)] (the lower end is reached while the register fills).  The reference's five runs lie inside (min
+    # 0 / -0.085 / -0.085 / -0.096, max 1.10 / 1.19 / 1.27 / 1.32); so must every one of our trajectories, and from 256 x 200 draws
+    # they come closer to the ends than 5 x 200 do.
+    k = np.arange(4)
+    lo, hi = -0.1 * k - 0.05, 1.0 + 0.1 * (k + 1) + 0.05          # + 0.05: the error feedback K e does not vanish in one step
+    assert np.all(g["state_min"] >= lo) and np.all(g["state_max"] <= hi)
     assert np.all(x >= lo) and np.all(x <= hi), (label, x.min(axis=(0, 1)), x.max(axis=(0, 1)))
-    # after the shift register has filled (4 steps) every run of the reference stays inside our per-state range as well
+    # after the shift register has filled (4 steps) every run of the reference stays inside our per-state range (+ 0.05)
     assert np.all(g["step_min"][4:] >= x[:, 4:].min(axis=(0, 1)) - 0.05) and np.all(g["step_max"][4:] <= x[:, 4:].max(axis=(0, 1)) + 0.05)
 
 

@@ -19,6 +19,7 @@
 
 #define TZ_GS_TILE 64            // generators per LDS tile
 #define TZ_GS_CHUNK 1024         // generators per workgroup (host plan)
+#define TZ_GS_MAXSUB 8           // matrix-core kernel, few trajectories: at most this many blocks share a chunk
 
 struct GsChunk { int seg, src, g0, g1; };        // generators [g0, g1) of the SORTED stack: tube seg, source src (-1 none, 0 e0, 1 + j zeta_j)
 
@@ -109,8 +110,180 @@ __global__ __launch_bounds__(256) void tz_genstack_kernel(GenstackParams q) {
   }
 }
 
+// ---- K1g on the matrix cores ---------------------------------------------------------------------------------------------------
+// Per chunk (one tube, one source) the hulls are |m0 + M Xi| summed over the generators, Xi = the source vectors of a tile of
+// trajectories: a [generator rows] x [n + m] x [trajectories] product with a tiny inner dimension.  With the m rows K M, K m0
+// appended to every generator on the host (P = n + m rows per generator, inner dimension P as well) rad^u comes out of the same
+// product and the kernel is v_mfma_f64_4x4x4 + one v_add_f64(|.|) per matrix instruction:
+//   * A operand = 4 GENERATORS x 4 inner entries of ONE component c (so the four rows of a tile are summed into the same
+//     accumulator); the four blocks of the instruction take the same A (LDS broadcast read) and four groups of 4 TRAJECTORIES
+//     (B operand = Xi, loaded once per workgroup, zero beyond the source's width: whatever finite number the A read picks up in
+//     the padding of the inner dimension is multiplied by 0); C operand = m0 of the 4 generators;
+//   * D = |.| -> acc[c][trajectory group]: P x NQ f64 accumulators per lane, folded over the 4 generator lanes (lane bits 4, 5)
+//     once at the end -- fixed order, deterministic;
+//   * the stack is laid out by the host exactly as the LDS tile ([group of 4 generators][component][generator][inner] then the
+//     m0 block), streamed global -> registers -> LDS double-buffered: the loads of tile t + 1 are in flight while tile t is
+//     multiplied, ONE barrier per tile;
+//   * SPLIT = false: a workgroup covers 256 trajectories (wave w: 64 w .. 64 w + 63, NQ = 4 groups of 16) and every wave walks all
+//     generators of the chunk; SPLIT = true (few trajectories: the stack is streamed once, the HBM-bound regime): all four waves
+//     take the same <= 64 trajectories and every fourth group of generators each, partial sums meet in LDS in wave order;
+//   * blockIdx -> (chunk, trajectory tile) so that the tiles of one chunk run on the same XCD (shared L2) back to back.
+struct GsChunkM { int seg, src, q0, nq; };       // groups [q0, q0 + nq) of 4 generators each (zero-padded), tube seg, source src
+
+struct GenstackMParams {
+  int B, n, m, N, nchunk, ntt, nsub;             // ntt = blocks per chunk: trajectory tiles of 256, or (SPLIT) nsub sub-ranges of its tiles
+  const double* recs;                            // groups of GD = 4 P (P + 1) doubles
+  const GsChunkM* chunks;
+  const double* e0;                              // B x n
+  const double* zeta;                            // B x N x (n+m)
+  double* partial;                               // nchunk x B x (n+m)
+};
+
+template <int P> struct GsTile {
+  static constexpr int GD = 4 * P * (P + 1);                                      // doubles per group of 4 generators
+  static constexpr int GT = (3072 / GD >= 64) ? 64 : (3072 / GD >= 32) ? 32 : (3072 / GD >= 16) ? 16 : (3072 / GD >= 8) ? 8 : 4;   // groups per tile (<= 24 KB)
+  static constexpr int ND2 = GT * GD / 2;                                         // double2 per tile
+  static constexpr int LD = (ND2 + 255) / 256;                                    // double2 per thread and tile
+};
+
+template <int P, int NQ, bool SPLIT>
+__global__ __launch_bounds__(256) void tz_genstack_mfma_kernel(GenstackMParams q) {
+  constexpr int KS = (P + 3) / 4, GD = GsTile<P>::GD, GT = GsTile<P>::GT, LD = GsTile<P>::LD;
+  __shared__ double2 tile2[2][GT * GD / 2 + 2];                   // +2: the last A read of a tile may run 3 doubles past the group
+  __shared__ double xred[SPLIT ? 3 * P * NQ * 16 : 1];
+  // (chunk, trajectory tile) of this block: the ntt tiles of a chunk are 8 blocks apart -> same XCD, consecutive waves of blocks
+  const int bid = blockIdx.x;
+  const int cgrp = bid / (8 * q.ntt), rem = bid % (8 * q.ntt);
+  const int chunk = cgrp * 8 + (rem & 7);
+  const int tt = SPLIT ? 0 : rem >> 3, sub = SPLIT ? rem >> 3 : 0;      // SPLIT: q.ntt counts the sub-blocks of a chunk (q.nsub)
+  if (chunk >= q.nchunk) return;
+  const GsChunkM ch = q.chunks[chunk];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int tb = SPLIT ? tt * 16 * NQ : tt * 256 + wave * 64;     // first trajectory of this wave
+  // B operands: lane (k = lane >> 4, trajectory lane & 15 of group qq) holds Xi[4 s + k] of its trajectory
+  double bx[KS][NQ];
+  {
+    const int k = lane >> 4, n = q.n, pc = q.n + q.m;
+    const int width = ch.src == 0 ? n : (ch.src > 0 ? pc : 0);
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+      const int b = tb + 16 * qq + (lane & 15);
+      const double* sv = ch.src == 0 ? q.e0 + (size_t)b * n : q.zeta + ((size_t)b * q.N + (ch.src > 0 ? ch.src - 1 : 0)) * pc;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) bx[s][qq] = (b < q.B && 4 * s + k < width) ? sv[4 * s + k] : 0.0;
+    }
+  }
+  double acc[P][NQ];
+#pragma unroll
+  for (int c = 0; c < P; ++c)
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) acc[c][qq] = 0.0;
+  const double2* src2 = reinterpret_cast<const double2*>(q.recs + (size_t)ch.q0 * GD);
+  // sub-range of the chunk's tiles this block walks (SPLIT only: nsub blocks share a chunk so that there are enough blocks to
+  // balance the chip; their partial sums are separate rows of `partial`, added by the reduce kernel in order)
+  const int ntile_all = (ch.nq + GT - 1) / GT;
+  const int t_lo = SPLIT ? (int)(((long long)ntile_all * sub) / q.nsub) : 0;
+  const int t_hi = SPLIT ? (int)(((long long)ntile_all * (sub + 1)) / q.nsub) : ntile_all;
+  const int ntile = t_hi - t_lo;
+  double2 stA[LD], stB[LD];                                      // two tiles in flight: HBM latency is longer than one tile's products
+  auto fetch = [&](double2 (&stage)[LD], int tl) {               // global -> registers (tile t_lo + tl), nothing waits for it here
+    const int tg = t_lo + tl;
+    const int nd2 = min(GT, ch.nq - tg * GT) * (GD / 2);
+    const double2* s = src2 + (size_t)tg * (GT * GD / 2);
+#pragma unroll
+    for (int i = 0; i < LD; ++i) { const int e = t + 256 * i; stage[i] = (e < nd2) ? s[e] : make_double2(0.0, 0.0); }
+  };
+  auto park = [&](const double2 (&stage)[LD], int buf) {         // registers -> LDS
+#pragma unroll
+    for (int i = 0; i < LD; ++i) { const int e = t + 256 * i; if (e < GT * GD / 2) tile2[buf][e] = stage[i]; }
+  };
+  const int ai = (lane & 3) * P + (lane >> 4);                   // A: generator i = lane & 3, inner entry k = lane >> 4 (+ 4 s)
+  const int ci = 4 * P * P + (lane >> 4);                        // C (D layout): generator i = lane >> 4
+  auto products = [&](int tl) {
+    const double* buf = reinterpret_cast<const double*>(tile2[tl & 1]);
+    const int ng = min(GT, ch.nq - (t_lo + tl) * GT);
+    for (int g = SPLIT ? wave : 0; g < ng; g += SPLIT ? 4 : 1) {
+      const double* gb = buf + g * GD;
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        const double m0v = gb[ci + 4 * c];
+        double d[NQ];
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) d[qq] = m0v;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const double a = gb[c * 4 * P + ai + 4 * s];
+#pragma unroll
+          for (int qq = 0; qq < NQ; ++qq) d[qq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bx[s][qq], d[qq], 0, 0, 0);
+        }
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) acc[c][qq] += fabs(d[qq]);
+      }
+    }
+  };
+  if (t < 2) { tile2[0][GT * GD / 2 + t] = make_double2(0.0, 0.0); tile2[1][GT * GD / 2 + t] = make_double2(0.0, 0.0); }
+  if (ntile > 0) {
+    fetch(stA, 0);
+    if (ntile > 1) fetch(stB, 1);
+    park(stA, 0);
+    __syncthreads();
+    for (int tl = 0; tl < ntile; tl += 2) {                      // two tiles per trip: the register sets alternate statically
+      if (tl + 2 < ntile) fetch(stA, tl + 2);
+      products(tl);
+      if (tl + 1 < ntile) park(stB, 1);
+      __syncthreads();
+      if (tl + 1 < ntile) {
+        if (tl + 3 < ntile) fetch(stB, tl + 3);
+        products(tl + 1);
+        if (tl + 2 < ntile) park(stA, 0);
+        __syncthreads();
+      }
+    }
+  }
+  // fold the four generator lanes (lane bits 4 and 5), fixed order
+#pragma unroll
+  for (int c = 0; c < P; ++c)
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+      double v = acc[c][qq];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      acc[c][qq] = v;
+    }
+  if (SPLIT) {
+    if (wave > 0 && lane < 16) {
+#pragma unroll
+      for (int c = 0; c < P; ++c)
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) xred[(((wave - 1) * P + c) * NQ + qq) * 16 + lane] = acc[c][qq];
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) {
+        const int b = tb + 16 * qq + lane;
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+          double v = acc[c][qq];
+          for (int w = 0; w < 3; ++w) v += xred[((w * P + c) * NQ + qq) * 16 + lane];
+          if (b < q.B) q.partial[((size_t)(chunk * q.nsub + sub) * q.B + b) * P + c] = v;
+        }
+      }
+    }
+  } else if (lane < 16) {
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+      const int b = tb + 16 * qq + lane;
+      if (b < q.B) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) q.partial[((size_t)(chunk * q.nsub + sub) * q.B + b) * P + c] = acc[c][qq];
+      }
+    }
+  }
+}
+
 struct GsReduceParams {
-  int B, n, m, N, nseg;
+  int B, n, m, N, nseg, nsub;                    // nsub partial rows per chunk (1 unless the matrix-core kernel split the chunks)
   const int* seg_chunk_ptr;                      // nseg + 1: chunks of tube k are [ptr[k], ptr[k+1])
   const double* partial;
   const double* c0; const double* cE; const double* cZ;   // nseg x n, nseg x n x n, nseg x N x n x (n+m) (cZ may be null: all zero)
@@ -124,7 +297,7 @@ __global__ void tz_genstack_reduce_kernel(GsReduceParams q) {
   if (gid >= (size_t)q.B * q.nseg * p) return;
   const int c = (int)(gid % p), k = (int)((gid / p) % q.nseg), b = (int)(gid / ((size_t)p * q.nseg));
   double a = 0.0;
-  for (int chn = q.seg_chunk_ptr[k]; chn < q.seg_chunk_ptr[k + 1]; ++chn) a += q.partial[((size_t)chn * q.B + b) * p + c];   // fixed order
+  for (int chn = q.seg_chunk_ptr[k] * q.nsub; chn < q.seg_chunk_ptr[k + 1] * q.nsub; ++chn) a += q.partial[((size_t)chn * q.B + b) * p + c];   // fixed order
   if (c < q.n) {
     q.radx[((size_t)b * q.nseg + k) * q.n + c] = a;
     double ce = q.c0[k * q.n + c];

@@ -72,7 +72,8 @@ struct IpmParams {
   FuseParams F;               // F.on != 0: whole closed-loop step in this launch (q, h, prestatus above are then unused)
 };
 
-enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_CH_UPD = 8, PH_CH_DIAG = 9, PH_CH_PANEL = 10, PH_CH_BAR = 11, PH_PROLOGUE = 12, PH_EPILOGUE = 13, PH_GRAM_LOOP = 14, PH_GRAM_RED = 15, PH_GRAM_BAR = 16, PH_GRAM_RMW = 17, PH_TUBE = 18, PH_WARM = 19, PH_TOP = 20, PH_STEP = 21, PH_COUNT = 22 };
+enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_CH_UPD = 8, PH_CH_DIAG = 9, PH_CH_PANEL = 10, PH_CH_BAR = 11, PH_PROLOGUE = 12, PH_EPILOGUE = 13, PH_GRAM_LOOP = 14, PH_GRAM_RED = 15, PH_GRAM_BAR = 16, PH_GRAM_RMW = 17, PH_TUBE = 18, PH_WARM = 19, PH_TOP = 20, PH_STEP = 21,
+       PH_RD_A = 22, PH_RD_B = 23, PH_RD_C = 24, PH_EPI_A = 25, PH_EPI_B = 26, PH_MAPS_Q = 27, PH_WARM_A = 28, PH_WARM_B = 29, PH_TEST = 30, PH_COUNT = 32 };   // 22 ..: finer stamps of the fixed part (diagnostic build)
 
 __device__ inline int tz_qprefix(int I) {   // number of quads in tile rows < I (row I has (I>>2)+1 quads)
   int a = I >> 2, b = I & 3;
@@ -1073,6 +1074,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     __syncthreads();
     TZ_STAMP(PH_TUBE);
     for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? csr_row(F.qmap, c, thl) : 0.0; if (src != 2) xv[c] = 0.0; }
+    TZ_STAMP(PH_MAPS_Q);
     int bad = 0;
     for (int r = t; r < F.npar; r += TZ_THREADS) {
       const double v = csr_row(F.parmap, r, thl);
@@ -1093,13 +1095,17 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
 
   // exact dual residual rd = P x + q + G'lam into rdv (used at the start and to confirm convergence)
   auto exact_rd = [&]() {
+    TZ_STAMP(PH_TEST);
     TZ_ROWS(k, r) vin[r] = l_[k];
     __syncthreads();
+    TZ_STAMP(PH_RD_A);
     if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part);     // P x by wave 0 (stays in `part` for the objective)
     else tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);                                   // G'lambda by waves 1-3
     __syncthreads();
+    TZ_STAMP(PH_RD_B);
     if (t < nzp) rdv[t] = (t < nz) ? (tz_ell_colsum(pl, cseg) + qv[t]) + part[t] : 0.0;
     __syncthreads();
+    TZ_STAMP(PH_RD_C);
   };
 
   // A solve that does not end in TZ_SOLVED (in practice: the aggressive fraction to the boundary collapsing mu before the
@@ -1139,10 +1145,12 @@ retry_solve:
     // G x of the starting point: inside a launch gx_ still holds it (it followed x through the iterations of the previous
     // step); it is formed afresh every eighth step so that rounding does not accumulate along a trajectory
     if (src != 2 || (step & 7) == 0 || retried || shifted) { tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
+    TZ_STAMP(PH_WARM_A);
     double viol = 0.0;
     TZ_ROWS(k, r) { const double hv = TZ_H(k, r); viol = fmax(viol, TZ_GX(k, r) - hv); sch = fmax(sch, fabs(hv)); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
     tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red, rpar);      // also the scales of the stopping test
+    TZ_STAMP(PH_WARM_B);
     const double sig = fmin(fmax(pk.warm_floor, pk.warm_gain * viol), pk.warm_cap);
     const double sig2 = sig * sig;
     TZ_ROWS(k, r) {                  // slack >= sig, multiplier >= sig^2 / slack: onto the central path of mu = sig^2 where the pair was
@@ -1187,6 +1195,9 @@ retry_solve:
   status = skip ? 3 : (okf ? 1 : 2);
   TZ_STAMP(PH_WARM);
   bool px_in_part = false;                  // `part` holds the partial sums of P x for the final x (left there by exact_rd)
+  // diagonal-shift level of this solve (0: none), raised when a factorisation breaks down; the cold retry of a failed solve starts at
+  // level 2 (1e-6): a breakdown the pivot test does not see (tiny positive pivots, a garbage step) is what made the first one fail
+  int rlev = retried ? 2 : 0;
 #if TZ_PRIO_GLUE
   __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1229,6 +1240,13 @@ retry_solve:
     TZ_ROWS(k, r) { is_[k] = tz_recip(s_[k]); il_[k] = tz_recip(l_[k]); w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
     __syncthreads();
     TZ_STAMP(PH_TOP);
+    bool okc;
+    bool have_y = false;                                // tmpz holds y = inv(L) r1 (forward substitution done while factoring)
+    // A factorisation that breaks down (degenerate problems late in the solve: the weights of active and inactive rows are 1e18
+    // apart and H loses definiteness in rounding) raises the diagonal-shift level -- 1 .. 4 = 1e-9, 1e-6, 1e-3, 1, kept for the
+    // rest of the solve -- and the iteration is repeated from the same point (it counts as an iteration).  A shifted H only damps
+    // the Newton step; the residuals are always exact.  `rlev` is uniform (scalar register); level 0, the normal case, costs one
+    // scalar branch.
 #if TZ_PRIO_ELEM
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1236,13 +1254,18 @@ retry_solve:
     __syncthreads();
     TZ_STAMP(PH_FORM);
     TZ_FRESH_T();
+    if (rlev != 0) {
+      const double rx = (rlev == 1) ? 1e-9 : (rlev == 2) ? 1e-6 : (rlev == 3) ? 1e-3 : 1.0;
+      for (int c = t; c < nz; c += TZ_THREADS) {
+        const int I = c >> 2, i = c & 3;
+        Hq[TT ? (size_t)(((I * (I + 1)) >> 1) + I) * p.TS + 5 * i : (size_t)tz_hidx(c, c)] += rx;
+      }
+    }
     // ---- predictor (rc = s*lam):  H dx = -(P x + q) - G'(w rp).  The factorisation of H and the two products on the right
     // are independent: with chol1 wave 0 factors while waves 1-3 form the right-hand side.
     TZ_ROWS(k, r) vin[r] = w_[k] * rp_[k];
     if (t == 0) { flag[2] = 0; flag[3] = 0; }        // columns factored / waves done with the right-hand side
     __syncthreads();
-    bool okc;
-    bool have_y = false;                                // tmpz holds y = inv(L) r1 (forward substitution done while factoring)
     if (!TT && p.chol1) {
       if (wave0) {
 #if TZ_PRIO
@@ -1297,7 +1320,14 @@ retry_solve:
       else okc = tz_cholesky(p, Hq, dinv, flag, (PROF && t == 0) ? acc_ph : nullptr);
       TZ_STAMP(PH_CHOL);
     }
-    if (!okc) { status = 2; break; }
+    if (!okc) {
+      if (rlev >= 4) { status = 2; break; }
+      rlev = __builtin_amdgcn_readfirstlane(rlev + 1);
+      __syncthreads();                                 // every thread has read the failure flag
+      if (t == 0) flag[0] = 0;
+      __syncthreads();
+      continue;
+    }
     TZ_FRESH_T();
     if constexpr (TT) TZ_TT_SOLVE(p, Hq, dinv, r1v, tmpz, dxv);
     else if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, have_y ? tmpz : r1v, dxv, have_y); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
@@ -1458,6 +1488,7 @@ retry_solve:
     } else
     for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = cDz[c] * xv[F.fin.vpos ? F.fin.vpos[c] : c];     // v in the caller's order
     __syncthreads();
+    TZ_STAMP(PH_EPI_A);
     double acc = 0.0, z1 = 0.0, z2 = 0.0;
     if (want_cost) {
       for (int c = t; c < nz; c += TZ_THREADS) acc += xv[c] * (0.5 * (px_in_part ? part[c] : tz_gemvT_get(part, nzp, c)) + qv[c]);
@@ -1492,6 +1523,7 @@ retry_solve:
       }
     }
     __syncthreads();
+    TZ_STAMP(PH_EPI_B);
     if (t < 64) {
       const PlantParams& Q = F.plant;
       double xn = 0.0, xb = 0.0;

@@ -451,10 +451,12 @@ struct tz_genstack {
   int device = 0, n = 0, m = 0, N = 0, nseg = 0, rec = 0, nchunk = 0;
   int64_t G = 0;
   std::vector<int> seg_ptr;                 // literal order
-  DevBuf<double> recs_sorted, recs_lit, c0, cE, cZ, K, partial, in_e0, in_zeta, o_c, o_rx, o_ru, o_Z;
+  DevBuf<double> recs_sorted, recs_lit, recs_mf, c0, cE, cZ, K, partial, in_e0, in_zeta, o_c, o_rx, o_ru, o_Z;
   DevBuf<int> src_lit, seg_chunk_ptr;
   DevBuf<GsChunk> chunks;
-  int Bcap = 0;
+  DevBuf<GsChunkM> chunks_m;                // matrix-core layout (tz_genstack_mfma_kernel): groups of 4 generators, K rows appended
+  bool mfma = false;
+  size_t pcap = 0;                          // doubles allocated for `partial`
   bool have_cZ = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -498,6 +500,41 @@ int tz_genstack_create(int device, const tz_genstack_desc* d, tz_genstack** out)
     scp[k + 1] = (int)chunks.size();
   }
   g->nchunk = (int)chunks.size();
+  // matrix-core layout of the sorted stack (dimensions with a compiled instance): per group of 4 generators (a chunk is padded
+  // with zero generators) [component c < P][generator i < 4][inner k < P] of Mext = [M; K M], then [c][i] of m0ext = [m0; K m0]
+  g->mfma = (p >= 3 && p <= 7) && !getenv("TZ_GS_VALU");
+  if (g->mfma && !chunks.empty()) {
+    const int GD = 4 * p * (p + 1);
+    std::vector<GsChunkM> cm; std::vector<double> mf;
+    std::vector<double> ext((size_t)p * (p + 1));
+    for (const GsChunk& ch : chunks) {
+      const int ng = ch.g1 - ch.g0, nq = (ng + 3) / 4;
+      const size_t q0 = mf.size() / GD;
+      mf.resize(mf.size() + (size_t)nq * GD, 0.0);
+      for (int gi = 0; gi < ng; ++gi) {
+        const double* r = &srt[(size_t)(ch.g0 + gi) * rec];            // [m0 (n) | M (n x p)]
+        for (int c = 0; c < p; ++c) {
+          double m0e = 0.0;
+          if (c < n) m0e = r[c]; else for (int i = 0; i < n; ++i) m0e += d->K[(size_t)(c - n) * n + i] * r[i];
+          ext[(size_t)c * (p + 1)] = m0e;
+          for (int k = 0; k < p; ++k) {
+            double v = 0.0;
+            if (c < n) v = r[n + c * p + k]; else for (int i = 0; i < n; ++i) v += d->K[(size_t)(c - n) * n + i] * r[n + i * p + k];
+            ext[(size_t)c * (p + 1) + 1 + k] = v;
+          }
+        }
+        double* gb = &mf[(q0 + gi / 4) * GD];
+        const int i4 = gi & 3;
+        for (int c = 0; c < p; ++c) {
+          for (int k = 0; k < p; ++k) gb[c * 4 * p + i4 * p + k] = ext[(size_t)c * (p + 1) + 1 + k];
+          gb[4 * p * p + 4 * c + i4] = ext[(size_t)c * (p + 1)];
+        }
+      }
+      cm.push_back(GsChunkM{ch.seg, ch.src, (int)q0, nq});
+    }
+    for (double v : mf) if (!std::isfinite(v)) TZ_FAIL(TZ_ERR_INVALID, "non-finite generator entry");
+    TZ_HIP(g->recs_mf.upload(mf)); TZ_HIP(g->chunks_m.upload(cm));
+  }
   TZ_HIP(g->recs_lit.upload(lit)); TZ_HIP(g->recs_sorted.upload(srt));
   TZ_HIP(g->src_lit.upload(d->src, (size_t)std::max<int64_t>(G, 1)));
   if (chunks.empty()) chunks.push_back(GsChunk{0, -1, 0, 0});
@@ -548,15 +585,38 @@ static int gs_eval(tz_genstack* g, int B, const double* de0, const double* dz, d
   const int n = g->n, m = g->m, p = n + m;
   GenstackParams q{B, n, m, g->N, g->nseg, g->nchunk, g->rec, g->recs_sorted.p, g->chunks.p, g->K.p, de0, dz, g->partial.p};
   const dim3 grid((unsigned)g->nchunk, (unsigned)((B + 255) / 256));
+  int nsub = 1;
   TZ_HIP(hipEventRecord(g->ev0, st));
-  if (g->nchunk > 0) {
+  if (g->nchunk > 0 && g->mfma) {
+    // few trajectories: every wave takes all of them and a quarter of the generators (the stack is streamed once: HBM-bound);
+    // many: 256 per workgroup, the stack is re-read from L2 by the tiles of a chunk, which share an XCD
+    const bool split = B <= 64;
+    const int nq = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    nsub = split ? std::min(TZ_GS_MAXSUB, std::max(1, (2048 + g->nchunk - 1) / g->nchunk)) : 1;   // >= ~2000 blocks for the chip to balance
+    const int ntt = split ? nsub : (B + 255) / 256;
+    GenstackMParams qm{B, n, m, g->N, g->nchunk, ntt, nsub, g->recs_mf.p, g->chunks_m.p, de0, dz, g->partial.p};
+    const dim3 gm((unsigned)(((g->nchunk + 7) / 8) * 8 * ntt));
+#define TZ_GS_LAUNCH(PP) do { \
+      if (!split) hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 4, false>), gm, dim3(256), 0, st, qm); \
+      else if (nq == 1) hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 1, true>), gm, dim3(256), 0, st, qm); \
+      else if (nq == 2) hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 2, true>), gm, dim3(256), 0, st, qm); \
+      else hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 4, true>), gm, dim3(256), 0, st, qm); } while (0)
+    switch (p) {
+      case 3: TZ_GS_LAUNCH(3); break;
+      case 4: TZ_GS_LAUNCH(4); break;
+      case 5: TZ_GS_LAUNCH(5); break;
+      case 6: TZ_GS_LAUNCH(6); break;
+      default: TZ_GS_LAUNCH(7); break;
+    }
+#undef TZ_GS_LAUNCH
+  } else if (g->nchunk > 0) {
     if (n == 2 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<2, 1>), grid, dim3(256), 0, st, q);
     else if (n == 4 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<4, 1>), grid, dim3(256), 0, st, q);
     else if (n == 5 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<5, 1>), grid, dim3(256), 0, st, q);
     else hipLaunchKernelGGL((tz_genstack_kernel<0, 0>), grid, dim3(256), 0, st, q);
   }
   TZ_HIP(hipEventRecord(g->ev1, st));
-  GsReduceParams r{B, n, m, g->N, g->nseg, g->seg_chunk_ptr.p, g->partial.p, g->c0.p, g->cE.p, g->have_cZ ? g->cZ.p : nullptr, de0, dz, dc, drx, dru};
+  GsReduceParams r{B, n, m, g->N, g->nseg, nsub, g->seg_chunk_ptr.p, g->partial.p, g->c0.p, g->cE.p, g->have_cZ ? g->cZ.p : nullptr, de0, dz, dc, drx, dru};
   const size_t total = (size_t)B * g->nseg * p;
   hipLaunchKernelGGL(tz_genstack_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
   TZ_HIP(hipGetLastError());
@@ -572,7 +632,7 @@ int tz_genstack_intervals(tz_genstack* g, int32_t B, const double* e0, const dou
   const double *de0 = nullptr, *dz = nullptr;
   int rc = gs_inputs(g, B, e0, zeta, mem, &de0, &dz);
   if (rc) return rc;
-  if (B > g->Bcap) { TZ_HIP(g->partial.alloc((size_t)g->nchunk * B * p)); g->Bcap = B; }
+  { const size_t need = (size_t)std::max(g->nchunk, 1) * (B <= 64 ? TZ_GS_MAXSUB : 1) * B * p; if (need > g->pcap) { TZ_HIP(g->partial.alloc(need)); g->pcap = need; } }
   double *dc = centre, *drx = rad_x, *dru = rad_u;
   if (mem == TZ_MEM_HOST) {
     TZ_HIP(g->o_c.alloc((size_t)B * g->nseg * n)); TZ_HIP(g->o_rx.alloc((size_t)B * g->nseg * n)); TZ_HIP(g->o_ru.alloc((size_t)B * g->nseg * m));
@@ -602,7 +662,7 @@ int tube_stack_theta(tz_problem* p, int B, const double* d_e0, hipStream_t st) {
     TZ_HIP(p->ts_c.alloc((size_t)B * g->nseg * n)); TZ_HIP(p->ts_rx.alloc((size_t)B * g->nseg * n)); TZ_HIP(p->ts_ru.alloc((size_t)B * g->nseg * m));
     p->ts_cap = B;
   }
-  if (B > g->Bcap) { TZ_HIP(g->partial.alloc((size_t)std::max(g->nchunk, 1) * B * pq)); g->Bcap = B; }
+  { const size_t need = (size_t)std::max(g->nchunk, 1) * (B <= 64 ? TZ_GS_MAXSUB : 1) * B * pq; if (need > g->pcap) { TZ_HIP(g->partial.alloc(need)); g->pcap = need; } }
   int rc = gs_eval(g, B, d_e0, p->ts_zeta.p, p->ts_c.p, p->ts_rx.p, p->ts_ru.p, st);
   if (rc) return rc;
   ThetaStackParams q{B, n, m, p->N, g->nseg, p->ntheta, p->ts_c.p, p->ts_rx.p, p->ts_ru.p, p->theta.p};
@@ -967,15 +1027,32 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   if (const char* e = getenv("TZ_WARM")) { p->warm_enabled = (e[0] != '0'); }
   if (const char* e = getenv("TZ_FUSE")) { p->fuse_enabled = (e[0] != '0'); }
   if ((size_t)p->pmax * p->n > p->hsize) p->fuse_enabled = false;   // tube scratch borrows the factor storage
-  if (const char* e = getenv("TZ_SHIFT_QUIET")) p->shift_quiet = atoi(e);
-  if (const char* e = getenv("TZ_WARM_FLOOR")) { double v = atof(e); if (v > 0) p->warm_floor = v; }
-  if (const char* e = getenv("TZ_WARM_GAIN")) p->warm_gain = atof(e);
-  if (const char* e = getenv("TZ_WARM_CAP")) { double v = atof(e); if (v > 0) p->warm_cap = v; }
-  if (const char* e = getenv("TZ_MU_FACTOR")) p->mu_factor = atof(e);
-  if (const char* e = getenv("TZ_RES_FACTOR")) p->res_factor = atof(e);
-  if (const char* e = getenv("TZ_AFF_THR")) p->aff_thr = atof(e);
-  if (const char* e = getenv("TZ_AFF_MU")) p->aff_mu = atof(e);
-  if (const char* e = getenv("TZ_STEP_FRAC")) { double v = atof(e); if (v > 0 && v < 1) p->step_frac = v; }
+  // experiment switches (tools/): the same ranges as the setters (tz_problem_set_stopping / _warm_quiet / _warm_push) -- a value
+  // that does not parse or lies outside fails the create call instead of silently changing the solver's accuracy
+  {
+    auto envd = [](const char* name, double lo, bool lo_open, double hi, double& dst) -> bool {
+      const char* e = getenv(name);
+      if (!e) return true;
+      char* end = nullptr;
+      const double v = strtod(e, &end);
+      if (end == e || *end != '\0' || !(lo_open ? v > lo : v >= lo) || !(v <= hi)) return false;
+      dst = v;
+      return true;
+    };
+    double sq = (double)p->shift_quiet;
+    if (!envd("TZ_SHIFT_QUIET", 0.0, false, 1e9, sq)) TZ_FAIL(TZ_ERR_INVALID, "TZ_SHIFT_QUIET must be an integer >= 0");
+    p->shift_quiet = (int)sq;
+    if (!envd("TZ_WARM_FLOOR", 0.0, true, 1e300, p->warm_floor)) TZ_FAIL(TZ_ERR_INVALID, "TZ_WARM_FLOOR must be > 0");
+    if (!envd("TZ_WARM_GAIN", 0.0, false, 1e300, p->warm_gain)) TZ_FAIL(TZ_ERR_INVALID, "TZ_WARM_GAIN must be >= 0");
+    if (!envd("TZ_WARM_CAP", 0.0, true, 1e300, p->warm_cap) || p->warm_cap < p->warm_floor) TZ_FAIL(TZ_ERR_INVALID, "TZ_WARM_CAP must be >= the floor");
+    if (!envd("TZ_MU_FACTOR", 0.0, true, 1.0, p->mu_factor)) TZ_FAIL(TZ_ERR_INVALID, "TZ_MU_FACTOR must be in (0, 1]");
+    if (!envd("TZ_RES_FACTOR", 1.0, false, 1e300, p->res_factor)) TZ_FAIL(TZ_ERR_INVALID, "TZ_RES_FACTOR must be >= 1");
+    if (!envd("TZ_AFF_THR", 0.0, true, 1.0, p->aff_thr)) TZ_FAIL(TZ_ERR_INVALID, "TZ_AFF_THR must be in (0, 1]");
+    if (!envd("TZ_AFF_MU", 0.0, true, 1.0, p->aff_mu)) TZ_FAIL(TZ_ERR_INVALID, "TZ_AFF_MU must be in (0, 1]");
+    double sf = p->step_frac;
+    if (!envd("TZ_STEP_FRAC", 0.0, true, 1.0, sf) || !(sf < 1.0)) TZ_FAIL(TZ_ERR_INVALID, "TZ_STEP_FRAC must be in (0, 1)");
+    p->step_frac = sf;
+  }
   if (p->prof) { TZ_HIP(p->prof_buf.alloc(PH_COUNT + 16)); TZ_HIP(hipMemset(p->prof_buf.p, 0, (PH_COUNT + 16) * sizeof(unsigned long long))); }
   TZ_HIP(p->work_buf.alloc(2));
   TZ_HIP(hipMemset(p->work_buf.p, 0, 2 * sizeof(unsigned long long)));

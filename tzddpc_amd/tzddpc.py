@@ -6,9 +6,13 @@ Same class / method surface as the reference (``tzddpc/tzddpc.py:11-377``):
                  . build_problem_simplified(k0, N, loss_cb, constr_cb) . solve(xbar0, e0, **kw)
 
 plus the batched entry points the GPU path exists for: ``solve_batch`` and ``simulate_batch``.
-Host code here only *assembles* (numpy, build time).  Every per-step number -- tube propagation,
-parameter application, the QP solve, trajectory recovery, the plant update -- is produced by HIP
-kernels behind the C-ABI (``include/tzddpc.h``); without the library or a GPU the calls raise.
+Host code here only *assembles* (numpy, build time).  Every per-step number of ``solve`` / ``solve_batch`` /
+``simulate_batch`` -- tube propagation, parameter application, the QP solve, trajectory recovery, the plant
+update -- is produced by HIP kernels behind the C-ABI (``include/tzddpc.h``); without the library or a GPU the
+calls raise.  One exception, stated where it happens: ``solve_simplified2`` (called by no reference example) takes
+``v``, ``xbar`` and the optimal value from the device and derives three reported quantities from them on the host with
+constant affine maps -- ``ubar = K xbar + v``, the centre of ``Ze[1]``, and the part of the ``"columns"`` regulariser
+that is linear in ``C_K^k e0``.
 """
 from __future__ import annotations
 
@@ -329,12 +333,12 @@ class TZDDPC(object):
             absCKpow=qp.tube.absCKpow, absKCKpow=qp.tube.absKCKpow, power=qp.tube.power, **shift, **opts)
         return nat, dict(elim=elim, scal=(D, E, c), row_of=row_of, qp=qp)
 
-    def _calibration_noise(self, Bn, T):
+    def _calibration_noise(self, Bn, T, seed=12345):
         """Disturbances of the build-time calibration loops: uniformly random vertices of W (what the examples' plants draw,
         ``examples/1.double_integrator_sim.py:85``); with many generators the 2^g candidate vertices are not enumerated but
         sampled directly as c + G s, s in {-1, 1}^g."""
         W = self.zonotopes.W
-        rng = np.random.default_rng(12345)
+        rng = np.random.default_rng(seed)
         if W.num_generators <= 12:
             Wv = W.compute_vertices()
             return Wv[rng.integers(0, Wv.shape[0], size=(Bn, T))]
@@ -375,29 +379,40 @@ class TZDDPC(object):
 
     def _choose_mu_factor(self, mode, A_model, B_model) -> float:
         """Complementarity target of the stopping test as a fraction of ``tol`` (``tz_problem_set_stopping``): a number, or
-        ``"auto"`` -- the loosest of 0.3, 0.1, 0.03, 0.01 that keeps the simulated closed loop (24 trajectories x 48 steps from
-        the centre of X0, vertex noise) within 2e-8 of the run with the tightest target 1e-3 in every state and input (50x inside
-        the north star's 1e-6; on the example's true plant, which is not the calibration's, the same settings measured 3e-8 ...
-        1.5e-7); the tightest if none does.  The distance to the solution of a degenerate problem goes like sqrt(mu): the double integrators
-        need 1e-3 ... 0.1, the LP-type losses (pulley, 5-dim) are at 1e-9 already with 0.3 and save an iteration per step."""
+        ``"auto"`` -- one notch tighter than the loosest of 0.3, 0.1, 0.03, 0.01, 1e-3, 1e-4 whose simulated closed loops stay within
+        1e-7 (relative; ten times inside the north star's 1e-6) of the run with the target 1e-5 in every state and input.  The loops: 24 trajectories
+        from the centre of X0 and 40 from random points around it (uniform, +-15 % of X's half-widths; starts the reference run
+        cannot solve are left out), 48 steps, vertex noise.  The random starts are what sets the target of the quadratic losses:
+        from the centre alone (round 2) the double integrators looked accurate at 0.01, from random starts their inputs are off by
+        2e-5 there and by 2e-6 at 1e-3 (transient steps with weakly active rows: the distance to the solution of a degenerate
+        problem goes like sqrt(mu)); they get 1e-4.  The LP-type losses (pulley, 5-dim) are at 1e-8 already with 0.3."""
         nat = self._native
         if mode != "auto":
             mu = float(mode)
         else:
             zon = self.zonotopes
-            Bn, T = 24, 48
-            noise = self._calibration_noise(Bn, T)
-            x0 = np.tile(np.asarray(zon.X0.center, float), (Bn, 1))
-            nat.set_stopping(100.0, 1e-3)
+            Bc, Br, T = 24, 40, 48
+            n = self.dim_x
+            noise = np.concatenate([self._calibration_noise(Bc, T), self._calibration_noise(Br, T, seed=777)])
+            Xi = zon.X.interval
+            half = 0.5 * (np.asarray(Xi.right_limit, float) - np.asarray(Xi.left_limit, float))
+            x0 = np.tile(np.asarray(zon.X0.center, float), (Bc + Br, 1))
+            x0[Bc:] += 0.15 * half[None] * np.random.default_rng(778).uniform(-1.0, 1.0, size=(Br, n))
+            nat.set_stopping(100.0, 1e-5)
             xr, ur, _, sr = nat.simulate_batch(x0, noise, A_model, B_model)
-            mu = 1e-3
-            if not np.any(sr != 0):
-                for cand in (0.3, 0.1, 0.03, 0.01):
+            ok = sr == 0
+            mu = 1e-5
+            if np.any(ok):
+                tx, tu = 1e-7 * (1 + np.abs(xr[ok]).max()), 1e-7 * (1 + np.abs(ur[ok]).max())
+                cands = (0.3, 0.1, 0.03, 0.01, 1e-3, 1e-4, 1e-5)
+                for ci, cand in enumerate(cands[:-1]):
                     nat.set_stopping(100.0, cand)
                     xc, uc, _, sc = nat.simulate_batch(x0, noise, A_model, B_model)
-                    if not np.any(sc != 0) and np.abs(xc - xr).max() <= 2e-8 * (1 + np.abs(xr).max()) \
-                            and np.abs(uc - ur).max() <= 2e-8 * (1 + np.abs(ur).max()):
-                        mu = cand
+                    if not np.any(sc[ok] != 0) and np.abs(xc[ok] - xr[ok]).max() <= tx and np.abs(uc[ok] - ur[ok]).max() <= tu:
+                        # safety margin: ONE notch tighter than the loosest target that passed.  The calibration sees 64 x 48 steps;
+                        # 512 x 30 steps from other random starts still found inputs 4e-6 off at the loosest passing target of the
+                        # double integrator (1e-3), none at the next (tests: test_calibration_holds_away_from_the_benchmark_start)
+                        mu = cands[ci + 1]
                         break
         nat.set_stopping(100.0, mu)
         return mu
@@ -412,8 +427,10 @@ class TZDDPC(object):
         identified centre are also (near) best on the example's true plant (C oracle, both plants: double integrator N=20
         0.83 -> 0.46-0.51 factorisations per step in the driver window, N=40 0.95 -> 0.45-0.49)."""
         nat = self._native
-        if mode == "auto" and os.environ.get("TZ_WARM_GAIN"):
-            mode = (float(os.environ["TZ_WARM_GAIN"]), float(os.environ.get("TZ_WARM_CAP", "inf")))   # experiment switch
+        if mode == "auto" and os.environ.get("TZ_WARM_GAIN"):                     # experiment switch (tools/): same range as the setter
+            mode = (float(os.environ["TZ_WARM_GAIN"]), float(os.environ.get("TZ_WARM_CAP", "inf")))
+            if not (mode[0] >= 0.0 and mode[1] >= 1e-8):
+                raise ValueError(f"TZ_WARM_GAIN / TZ_WARM_CAP out of range: {mode}")
         if mode != "auto":
             gain, cap = (float(mode[0]), float(mode[1])) if isinstance(mode, (tuple, list)) else (float(mode), float("inf"))
         else:
