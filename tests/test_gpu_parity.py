@@ -618,7 +618,7 @@ def test_literal_tubes_dense_generators_and_collapsed_where_exact(built):
     boxedK, boxedD = ctl.MdataK, ctl.Mdelta
     ctl.MdataK, ctl.Mdelta = MatrixZonotope(dK.center, dK.generators), MatrixZonotope(dD.center, dD.generators)
     with pytest.raises(StructureError, match="literal problem"):       # horizon 6, full problem: ~1e5 decision-dependent generator entries
-        ctl.build_problem(6, common.loss_di, common.nocons)
+        ctl.build_problem(6, common.loss_di, common.nocons, dense="literal")     # (dense="auto" would switch to the cutting-plane form)
     N = 3
     ctl.horizon, ctl.k0 = N, None; ctl._gs_full = None
     Bn = 4
@@ -1104,3 +1104,89 @@ def test_build_without_calibration(built):
     ref = common.c_oracle_for(ctl).simulate_batch(x0, noise, A, B, threads=16)
     assert (dev["status"] == 0).all() and (ref["status"] == 0).all()
     np.testing.assert_allclose(dev["x"], ref["x"], atol=1e-6); np.testing.assert_allclose(dev["u"], ref["u"], atol=1e-6)
+
+
+def test_dense_generators_by_cutting_planes(built):
+    """Dense matrix-zonotope generators at Table-I scale: DI, Girard order-2 generators, build_problem_simplified(1, 20) -- 684 epigraph
+    variables in the literal form (reference tzddpc/tzddpc.py:243-355 with reduce(order > 1) at :126-128), beyond the 256 of the
+    device solver -- is built in cutting-plane form (sign-pattern rows added while the literal evaluation of the solutions, K1g on
+    the device, shows them violated).  (i) N = 4, k0 = 1, forced into the same form: the optimum of the oracle's literal
+    restatement.  (ii) N = 20: every solution satisfies the LITERAL tube constraints (evaluated generator by generator on the
+    device) and has the value of the same loop run with the oracle's solver and numpy separation; dense tubes are tighter than the
+    boxed ones, so the value cannot exceed the collapsed problem's.  (iii) a short closed loop against the host loop."""
+    from oracle import harness as H, literal as L
+    from oracle.qp_ipm import solve_qp
+    from tests.test_oracle_collapse import _cutting_plane_cpu
+    from tzddpc_amd import TZDDPC, Data, Theta
+    from tzddpc_amd.genstack import build_stack
+    from tzddpc_amd.harness import system
+    from tzddpc_amd.zonotope import MatrixZonotope
+    s, u, x, idn, rng = _oracle_setup("di_cc")
+    A, B, zon, T = system("di_cc")
+    n, m = B.shape
+    dK, dD = idn["MdataK_raw"].reduce(2), idn["Mdelta_raw"].reduce(2)
+    Xi, Ui = zon.X.interval, zon.U.interval
+
+    def controller(N, k0, **kw):
+        ctl = TZDDPC(Data(u, x))
+        ctl.build_zonotopes_theta(zon, theta=Theta(idn["K"], np.zeros_like(A), np.zeros_like(B)))
+        ctl.MdataK, ctl.Mdelta = MatrixZonotope(dK.center, dK.generators), MatrixZonotope(dD.center, dD.generators)
+        ctl.build_problem_simplified(k0, N, common.loss_di, common.nocons, **kw)
+        return ctl
+    # (i) small: literal optimum
+    N, k0 = 4, 1
+    ctl = controller(N, k0, dense="cuts")
+    assert ctl._cuts is not None and ctl.qp.nz <= 2 * N * m + 2
+    Bn = 6
+    x0 = np.tile(zon.X0.center, (Bn, 1)) + 0.05 * rng.standard_normal((Bn, n)); e0 = 0.02 * rng.standard_normal((Bn, n)); e0[0] = 0.0
+    out = ctl.solve_batch(x0, e0)
+    assert (out["status"] == 0).all()
+    for b in range(Bn):
+        q = L.to_qp(L.build_literal(idn["A"], idn["B"], dK, dD, idn["K"], s["W"], s["X"], s["U"], N, e0[b], x0[b], H.loss_di, None, k0))
+        r = solve_qp(q["P"], q["q"], q["A"], q["l"], q["u"], tol=1e-12)
+        assert r.status == "solved"
+        assert abs(out["cost"][b] - (r.obj + q["r"])) <= 1e-7 * (1 + abs(r.obj + q["r"]))
+        np.testing.assert_allclose(out["v"][b, 0], r.x[(N + 1) * n:(N + 1) * n + m], atol=REL * (1 + np.abs(r.x).max()))
+    # (ii) Table-I scale
+    N, k0 = 20, 1
+    ctl = controller(N, k0)                                        # dense="auto": 684 literal variables -> cutting planes
+    assert ctl._cuts is not None and ctl.qp.nz <= 2 * N * m + 2
+    Bn = 48
+    x0 = np.tile(zon.X0.center, (Bn, 1)) + 0.3 * rng.standard_normal((Bn, n)); e0 = 0.02 * rng.standard_normal((Bn, n))
+    out = ctl.solve_batch(x0, e0)
+    assert (out["status"] == 0).all() and ctl.num_cuts() > 0
+    tb = ctl.literal_tubes(e0, out["xbar"], out["v"])              # the literal tubes of the returned solutions, generator by generator
+    K = np.atleast_2d(idn["K"])
+    cx = out["xbar"][:, :N] + tb["center"]; cu = out["v"] + np.einsum("ji,bki->bkj", K, tb["center"])
+    assert np.all(cx + tb["rad_x"] <= Xi.right_limit + 1e-7) and np.all(cx - tb["rad_x"] >= Xi.left_limit - 1e-7)
+    assert np.all(cu + tb["rad_u"] <= Ui.right_limit + 1e-7) and np.all(cu - tb["rad_u"] >= Ui.left_limit - 1e-7)
+    st = build_stack(ctl.MdataK, ctl.Mdelta, idn["K"], zon.W, n, m, N, k0, nseg=N)
+    args = (idn["A"], idn["B"], np.asarray(dK.center), None, None, idn["K"], zon.W.center, zon.W.generators,
+            Xi.left_limit, Xi.right_limit, Ui.left_limit, Ui.right_limit, N, common.loss_di, common.nocons, k0)
+    for b in (0, 7, 23, 47):
+        cost, v, xb, rounds, ncut = _cutting_plane_cpu(args, st, K, np.asarray(Xi.left_limit), np.asarray(Xi.right_limit),
+                                                       np.asarray(Ui.left_limit), np.asarray(Ui.right_limit), x0[b], e0[b])
+        assert abs(out["cost"][b] - cost) <= 1e-7 * (1 + abs(cost)), (out["cost"][b], cost)
+        np.testing.assert_allclose(out["v"][b, 0], v[0], atol=REL * (1 + np.abs(v).max()))
+    boxed, _ = common.gpu_controller("di_n20_k1")                  # the same data set and gain with the boxes of reduce(1): looser tubes
+    ob = boxed.solve_batch(x0, e0)
+    assert np.all(out["cost"] <= ob["cost"] + 1e-6 * (1 + np.abs(ob["cost"])))
+    # a second call re-uses the cuts: no further rounds
+    ncuts = ctl.num_cuts()
+    ctl.solve_batch(x0, e0)
+    assert ctl.cut_rounds == 0 and ctl.num_cuts() == ncuts
+    # (iii) closed loop, 5 steps of 8 trajectories
+    Wv = zon.W.compute_vertices()
+    noise = Wv[np.random.default_rng(9).integers(0, Wv.shape[0], size=(8, 5))]
+    xs = np.tile(zon.X0.center, (8, 1))
+    sim = ctl.simulate_batch(xs, noise, A, B)
+    assert (sim["status"] == 0).all()
+    xx = xs[0].copy(); xbar = xx.copy(); e = np.zeros(n)
+    for t in range(5):
+        _, v, xb, _, _ = _cutting_plane_cpu(args, st, K, np.asarray(Xi.left_limit), np.asarray(Xi.right_limit),
+                                            np.asarray(Ui.left_limit), np.asarray(Ui.right_limit), xbar, e)
+        uu = v[0] + K @ e
+        np.testing.assert_allclose(sim["u"][0, t], uu, atol=REL * (1 + np.abs(uu).max()))
+        xx = A @ xx + B @ uu + noise[0, t]
+        xbar = xb[1]; e = xx - xbar
+        np.testing.assert_allclose(sim["x"][0, t + 1], xx, atol=REL * (1 + np.abs(xx).max()))

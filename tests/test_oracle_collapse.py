@@ -121,3 +121,73 @@ def test_product_literal_problem_matches_oracle_literal_for_dense_generators(N, 
         assert r.status == "solved" == ro.status
         assert abs(cost - (ro.obj + q["r"])) <= 1e-7 * (1 + abs(cost))
         np.testing.assert_allclose(r.x[:m], ro.x[(N + 1) * n:(N + 1) * n + m], atol=1e-6)
+
+
+def _cutting_plane_cpu(args, st, K, xl, xu, ul, uu, x0, e0, tol=1e-9, max_rounds=60):
+    """The cutting-plane loop of `TZDDPC._solve_with_cuts` with the oracle's solver and numpy separation standing in for the device
+    (same builder rows): returns (cost, v, xbar, rounds, number of patterns)."""
+    from oracle.qp_ipm import solve_qp
+    from tzddpc_amd.builder import build_parametric_qp, theta_reference
+    n, m, N = st.n, st.m, st.N
+    cuts = {}
+    for rounds in range(max_rounds):
+        qp = build_parametric_qp(*args, literal=st, cuts=cuts)
+        th = theta_reference(qp, x0, e0)
+        r = solve_qp(qp.P, qp.q0 + qp.Qt @ th, qp.A, qp.l0 + qp.Lt @ th, qp.u0 + qp.Ut @ th, tol=1e-12)
+        assert r.status == "solved", r.status
+        v = r.x[:N * m].reshape(N, m)
+        xbar = (qp.Phi @ x0 + qp.Gam @ r.x[:N * m]).reshape(N + 1, n)
+        zeta = np.concatenate([xbar[:N], v], axis=1)
+        xi = np.zeros((N + 2, n + m)); xi[1, :n] = e0; xi[2:] = zeta
+        val = st.m0 + np.einsum("gic,gc->gi", st.M, xi[st.src + 1])                 # every generator column
+        added = 0
+        for k in range(N):
+            sl = slice(int(st.seg_ptr[k]), int(st.seg_ptr[k + 1]))
+            c = st.c0[k] + st.cE[k] @ e0
+            rx = np.abs(val[sl]).sum(axis=0); ru = np.abs(val[sl] @ K.T).sum(axis=0)
+            cx = xbar[k] + c; cu = v[k] + K @ c
+            for kind, comps, cen, rad, lo, hi, vals in (("x", n, cx, rx, xl, xu, val), ("u", m, cu, ru, ul, uu, val @ K.T)):
+                for i in range(comps):
+                    if max(cen[i] + rad[i] - hi[i], lo[i] - (cen[i] - rad[i])) > tol * (1 + max(abs(lo[i]), abs(hi[i]))):
+                        fam = qp.families.get((k, kind, i))
+                        if fam:
+                            p = np.where(vals[np.asarray(fam), i] >= 0.0, 1.0, -1.0)
+                            if p.tobytes() not in {q.tobytes() for q in cuts.get((k, kind, i), [])}:
+                                cuts.setdefault((k, kind, i), []).append(p); added += 1
+        if added == 0:
+            cost = r.obj + qp.r0 + qp.r1 @ x0 + x0 @ qp.R2 @ x0
+            return cost, v, xbar, rounds, sum(len(c) for c in cuts.values())
+    raise AssertionError("cutting planes did not converge")
+
+
+@pytest.mark.parametrize("N,k0", [(3, None), (4, 1), (5, 2)])
+def test_cutting_plane_form_reaches_the_literal_optimum(N, k0):
+    """Dense generators beyond the literal problem's size are solved in cutting-plane form (`build_parametric_qp(..., cuts=...)`:
+    sign-pattern rows instead of one epigraph variable per generator entry).  On sizes where the oracle's literal restatement
+    (reference tzddpc/tzddpc.py:172-207 / :283-324, every entry an epigraph) is still solvable the loop must end at ITS optimum."""
+    from oracle import harness as H, literal as OL
+    from oracle.qp_ipm import solve_qp
+    from tests import common
+    from tzddpc_amd.genstack import build_stack
+    from tzddpc_amd.zonotope import MatrixZonotope as PMZ, Zonotope as PZ
+    s = H.system("di_cc"); rng = np.random.default_rng(25)
+    u, x = H.generate_trajectories(s["A"], s["B"], s["X0"], s["U"], s["W"], 1, s["T"], rng)
+    idn = H.identify(u, x, s["W"])
+    dK, dD = idn["MdataK_raw"].reduce(2), idn["Mdelta_raw"].reduce(2)
+    n, m = 2, 1
+    pK, pD = PMZ(np.asarray(dK.center), np.asarray(dK.generators)), PMZ(np.asarray(dD.center), np.asarray(dD.generators))
+    W = PZ(np.asarray(s["W"].center), np.asarray(s["W"].generators))
+    st = build_stack(pK, pD, idn["K"], W, n, m, N, k0, nseg=N)
+    Xi, Ui = s["X"].interval, s["U"].interval
+    args = (idn["A"], idn["B"], np.asarray(dK.center), None, None, idn["K"], W.center, W.generators,
+            Xi.left_limit, Xi.right_limit, Ui.left_limit, Ui.right_limit, N, common.loss_di, common.nocons, k0)
+    K = np.atleast_2d(idn["K"])
+    for b in range(3):
+        x0 = np.asarray(s["X0"].center) + 0.05 * rng.standard_normal(2); e0 = 0.02 * rng.standard_normal(2)
+        cost, v, xbar, rounds, ncut = _cutting_plane_cpu(args, st, K, np.asarray(Xi.left_limit), np.asarray(Xi.right_limit),
+                                                         np.asarray(Ui.left_limit), np.asarray(Ui.right_limit), x0, e0)
+        q = OL.to_qp(OL.build_literal(idn["A"], idn["B"], dK, dD, idn["K"], s["W"], s["X"], s["U"], N, e0, x0, H.loss_di, None, k0))
+        ro = solve_qp(q["P"], q["q"], q["A"], q["l"], q["u"], tol=1e-12)
+        assert ro.status == "solved"
+        assert abs(cost - (ro.obj + q["r"])) <= 1e-7 * (1 + abs(cost)), (cost, ro.obj + q["r"], rounds, ncut)
+        np.testing.assert_allclose(v[0], ro.x[(N + 1) * n:(N + 1) * n + m], atol=1e-6)

@@ -7,7 +7,7 @@ import torch
 from tests import common
 from tzddpc_amd.dist import vertex_noise
 names = ["formH", "chol", "solve", "gemvT", "gemvG", "elem", "total", "iters", "ch_upd", "ch_diag", "ch_panel", "ch_bar", "prologue", "epilogue", "gram_loop", "gram_red", "gram_bar", "gram_rmw", "tube", "warm", "top", "step",
-         "rd_a(vin+bar)", "rd_b(Px|G'lam)", "rd_c(colsum+bar)", "epi_a(v)", "epi_b(cost,xbar1)", "maps_q", "warm_a(shift,Gx)", "warm_b(reduce)", "test(top->rd)", "-", "w1_upd_i", "w1_upd_ii", "x34", "x35", "x36", "x37"]
+         "rd_a(vin+bar)", "rd_b(Px|G'lam)", "rd_c(colsum+bar)", "epi_a(v)", "epi_b(cost,xbar1)", "maps_q", "warm_a(shift,Gx)", "warm_b(reduce)", "test(top->rd)", "t1(rp loop)", "t2(reduce)", "t3(mu,recip)", "x34", "x35", "x36", "x37"]
 case = sys.argv[1] if len(sys.argv) > 1 else "di_n20"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ctl, (A, B, zon) = common.gpu_controller(case)

@@ -184,7 +184,7 @@ def newton_cost(qp: "ParametricQP") -> float:
 
 def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: int,
                         build_loss: Callable, build_constraints: Optional[Callable],
-                        k0: Optional[int] = None, epigraph: str = "auto", literal=None) -> ParametricQP:
+                        k0: Optional[int] = None, epigraph: str = "auto", literal=None, cuts=None) -> ParametricQP:
     """epigraph: "component" -- one variable t_{j,c} >= |zeta_{j,c}| per used component (2 rows each);
                  "aggregate" -- when Delta^delta is rank one (rho s'), every radius depends on t_j only through
                                 tau_j = s'|zeta_j|: one variable per step j and 2^(#components) sign rows
@@ -199,7 +199,14 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
              variable, `t >= |m0_i + M_i zeta_j|` (what cvxpy's canonicalisation of ``.interval`` does, reference ``:191-197``);
              the generators that depend on e0 only stay numeric: their radii reach the problem through theta's rho entries,
              which the device then takes from the stack (``tz_problem_attach_tube_stack``), not from the collapsed recursion.
-             DK / Dd are ignored.  Sized by the caller: N * (generators per tube) * (n + m) variables."""
+             DK / Dd are ignored.  Sized by the caller: N * (generators per tube) * (n + m) variables.
+    cuts:    (with `literal`) the CUTTING-PLANE form of the literal problem: no epigraph variables at all; the radius of a tube row,
+             sum_g |a_g(v, xbar0)| over its decision-dependent generators, is replaced by sum_g sigma_g a_g for every sign pattern
+             sigma in cuts[(k, "x" | "u", i)] -- each one a valid inequality for every parameter value (sum sigma a <= sum |a|), so
+             the rows are shared by all trajectories and steps like the rest of G; the caller adds the patterns that the literal
+             evaluation of a solution shows to be violated until none is (`TZDDPC` does, with K1g as the separation oracle).  The
+             problem keeps N m + (loss epigraphs) variables whatever the generator count.  `ParametricQP.families` lists, per
+             (k, kind, i), the generators of the row (indices into the tube's literal order) for the caller's sign look-up."""
     Ahat = np.asarray(Ahat, float); Bhat = np.asarray(Bhat, float)
     K = np.atleast_2d(np.asarray(K, float))
     n, m = Bhat.shape
@@ -269,6 +276,14 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
                 for j2 in range(m):
                     if np.any(KM[j2]):
                         lit_u.append((k, j2, g))
+    families = {}
+    if cuts is not None:
+        assert literal is not None, "cuts need the literal stack"
+        for (k, i, g) in lit_x:
+            families.setdefault((k, "x", i), []).append(g)
+        for (k, j2, g) in lit_u:
+            families.setdefault((k, "u", j2), []).append(g)
+        lit_x, lit_u = [], []                                # no epigraph variables: sign-pattern rows instead
     # ---- which |.| epigraphs are needed --------------------------------------------------------
     used = (np.abs(rxT).sum(axis=(0, 1)) + np.abs(ruT).sum(axis=(0, 1))) > 0      # (nt,)
     t_var = {}                       # (j, c) -> z index            (component form)
@@ -412,6 +427,24 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
 
     zeros_t = lambda: np.zeros(ntheta)
 
+    def gen_row(g, i, left):
+        """a_g = c + f.z + th.theta for row i of generator g (left = None) or of K g (left = K): what the literal epigraphs bound"""
+        j = int(literal.src[g]) - 1
+        rowM = literal.M[g][i] if left is None else left[i] @ literal.M[g]
+        c_ = float(literal.m0[g][i] if left is None else left[i] @ literal.m0[g])
+        f = np.zeros(nz); f[:N * m] = rowM[:n] @ Gam[j]; f[j * m:(j + 1) * m] += rowM[n:]
+        th = zeros_t(); th[[ix_x0(cc) for cc in range(n)]] = rowM[:n] @ Phi[j]
+        return c_, f, th
+
+    def cut_terms(key, sigma):
+        """sum_g sigma_g a_g over the family `key`: (constant, z coefficients, theta coefficients)"""
+        k, kind, i = key
+        c_s, f_s, th_s = 0.0, np.zeros(nz), zeros_t()
+        for sg, g in zip(sigma, families[key]):
+            c_, f, th = gen_row(g, i, None if kind == "x" else K)
+            c_s += sg * c_; f_s += sg * f; th_s += sg * th
+        return c_s, f_s, th_s
+
     # ---- tube rows (``:189-209``) --------------------------------------------------------------
     for k in range(N):
         for i in range(n):
@@ -438,6 +471,10 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
             add_row(f"Xub[{k},{i}]", zc + tt, -np.inf, zeros_t(), xu[i] - cn[k, i] - rx0[k, i], -(base + rxk + th_abs))
             # lower: xbar + c - rad >= xl
             add_row(f"Xlb[{k},{i}]", zc - tt, xl[i] - cn[k, i] + rx0[k, i], -(base - rxk - th_abs), np.inf, zeros_t())
+            for ci_, sigma in enumerate((cuts or {}).get((k, "x", i), [])):     # cutting planes: rad >= sum_g sigma_g a_g
+                c_s, f_s, th_s = cut_terms((k, "x", i), sigma)
+                add_row(f"Xub[{k},{i}]c{ci_}", zc + f_s, -np.inf, zeros_t(), xu[i] - cn[k, i] - rx0[k, i] - c_s, -(base + rxk + th_abs + th_s))
+                add_row(f"Xlb[{k},{i}]c{ci_}", zc - f_s, xl[i] - cn[k, i] + rx0[k, i] + c_s, -(base - rxk - th_abs - th_s), np.inf, zeros_t())
         Kcn = K @ cn[k]
         for j2 in range(m):
             zc = np.zeros(nz); zc[k * m + j2] = 1.0
@@ -460,6 +497,10 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
             ruk = zeros_t(); ruk[ix_ru(k, j2)] = 1.0
             add_row(f"Uub[{k},{j2}]", zc + tt, -np.inf, zeros_t(), uu[j2] - Kcn[j2] - ru0[k, j2], -(base + ruk + th_abs))
             add_row(f"Ulb[{k},{j2}]", zc - tt, ul[j2] - Kcn[j2] + ru0[k, j2], -(base - ruk - th_abs), np.inf, zeros_t())
+            for ci_, sigma in enumerate((cuts or {}).get((k, "u", j2), [])):
+                c_s, f_s, th_s = cut_terms((k, "u", j2), sigma)
+                add_row(f"Uub[{k},{j2}]c{ci_}", zc + f_s, -np.inf, zeros_t(), uu[j2] - Kcn[j2] - ru0[k, j2] - c_s, -(base + ruk + th_abs + th_s))
+                add_row(f"Ulb[{k},{j2}]c{ci_}", zc - f_s, ul[j2] - Kcn[j2] + ru0[k, j2] + c_s, -(base - ruk - th_abs - th_s), np.inf, zeros_t())
     # ---- tau_j >= s'|zeta_j|  (aggregate form): one row per sign pattern of the components with s_c > 0 -------------
     if aggregate:
         import itertools
@@ -565,6 +606,8 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
     if literal is not None:
         from .genstack import restrict_to_e0
         out.estack = restrict_to_e0(literal, N)
+    if cuts is not None:
+        out.families = families
     return out
 
 

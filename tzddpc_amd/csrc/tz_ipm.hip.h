@@ -73,7 +73,7 @@ struct IpmParams {
 };
 
 enum { PH_FORM = 0, PH_CHOL = 1, PH_SOLVE = 2, PH_GEMVT = 3, PH_GEMV = 4, PH_ELEM = 5, PH_TOTAL = 6, PH_CH_UPD = 8, PH_CH_DIAG = 9, PH_CH_PANEL = 10, PH_CH_BAR = 11, PH_PROLOGUE = 12, PH_EPILOGUE = 13, PH_GRAM_LOOP = 14, PH_GRAM_RED = 15, PH_GRAM_BAR = 16, PH_GRAM_RMW = 17, PH_TUBE = 18, PH_WARM = 19, PH_TOP = 20, PH_STEP = 21,
-       PH_RD_A = 22, PH_RD_B = 23, PH_RD_C = 24, PH_EPI_A = 25, PH_EPI_B = 26, PH_MAPS_Q = 27, PH_WARM_A = 28, PH_WARM_B = 29, PH_TEST = 30, PH_COUNT = 32 };   // 22 ..: finer stamps of the fixed part (diagnostic build)
+       PH_RD_A = 22, PH_RD_B = 23, PH_RD_C = 24, PH_EPI_A = 25, PH_EPI_B = 26, PH_MAPS_Q = 27, PH_WARM_A = 28, PH_WARM_B = 29, PH_TEST = 30, PH_T1 = 31, PH_T2 = 32, PH_T3 = 33, PH_COUNT = 34 };   // 22 ..: finer stamps of the fixed part (diagnostic build)
 
 __device__ inline int tz_qprefix(int I) {   // number of quads in tile rows < I (row I has (I>>2)+1 quads)
   int a = I >> 2, b = I & 3;
@@ -1094,18 +1094,40 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   TZ_STAMP(PH_PROLOGUE);
 
   // exact dual residual rd = P x + q + G'lam into rdv (used at the start and to confirm convergence)
-  auto exact_rd = [&]() {
+  // staged == true: vin already holds lambda and a barrier has passed since (the warm start stages it; the reduction at the top of
+  // the first iteration is the barrier).  Returns max |rd| (every thread).
+  auto exact_rd = [&](bool staged) -> double {
     TZ_STAMP(PH_TEST);
-    TZ_ROWS(k, r) vin[r] = l_[k];
-    __syncthreads();
+    if (!staged) {
+      TZ_ROWS(k, r) vin[r] = l_[k];
+      __syncthreads();
+    }
     TZ_STAMP(PH_RD_A);
     if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part);     // P x by wave 0 (stays in `part` for the objective)
     else tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);                                   // G'lambda by waves 1-3
     __syncthreads();
     TZ_STAMP(PH_RD_B);
-    if (t < nzp) rdv[t] = (t < nz) ? (tz_ell_colsum(pl, cseg) + qv[t]) + part[t] : 0.0;
-    __syncthreads();
+    double e1 = 0.0;
+    if (nzp <= 64) {
+      // all columns sit in wave 0: its maximum is the workgroup's -- one wave reduction, one LDS hop, one barrier (instead of store,
+      // barrier, re-read, four wave reductions, exchange, barrier)
+      if (wave0) {
+        const double v = (t < nz) ? (tz_ell_colsum(pl, cseg) + qv[t]) + part[t] : 0.0;
+        if (t < nzp) rdv[t] = v;
+        e1 = tz_wave_reduce<RED_MAX>(fabs(v));
+        if (t == 0) red[14] = e1;                      // (rewritten by the next test only: there is always a barrier in between)
+      }
+      __syncthreads();
+      e1 = red[14];
+    } else {
+      if (t < nzp) rdv[t] = (t < nz) ? (tz_ell_colsum(pl, cseg) + qv[t]) + part[t] : 0.0;
+      __syncthreads();
+      double e2 = 0, e3 = 0;
+      for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
+      tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX, 1>(e1, e2, e3, red, rpar);
+    }
     TZ_STAMP(PH_RD_C);
+    return e1;
   };
 
   // A solve that does not end in TZ_SOLVED (in practice: the aggressive fraction to the boundary collapsing mu before the
@@ -1156,6 +1178,7 @@ retry_solve:
     TZ_ROWS(k, r) {                  // slack >= sig, multiplier >= sig^2 / slack: onto the central path of mu = sig^2 where the pair was
       s_[k] = fmax(TZ_H(k, r) - TZ_GX(k, r), sig);           // below it; an inactive row keeps its multiplier ~ 0 instead of being
       l_[k] = fmax(l_[k], sig2 * tz_recip(s_[k]));           // lifted to sig (which alone set mu ~ sig * mean slack: 6 more iterations)
+      vin[r] = l_[k];                                        // staged for the stopping test of the starting point (exact_rd at it == 0)
     }
   }
   if (!warm) {
@@ -1189,8 +1212,9 @@ retry_solve:
   }
   }
   // scales of the stopping test: parked in LDS (two spare slots of the reduction buffer) instead of four registers for the whole solve
-  if (t == 0) { red[12] = 1.0 + scq; red[13] = 1.0 + sch; }
-  __syncthreads();
+  // (every thread stores the same two numbers -- the reductions above leave them in all threads -- so no barrier is needed for them:
+  // a thread reads what its own wave wrote, and the first reader sits behind the barrier of the next reduction anyway)
+  red[12] = 1.0 + scq; red[13] = 1.0 + sch;
 
   status = skip ? 3 : (okf ? 1 : 2);
   TZ_STAMP(PH_WARM);
@@ -1220,16 +1244,16 @@ retry_solve:
     // mu already pass the test
     double nrp = 0, sl = 0, z0 = 0;
     TZ_ROWS(k, r) { rp_[k] = TZ_GX(k, r) + s_[k] - TZ_H(k, r); nrp = fmax(nrp, fabs(rp_[k])); sl += s_[k] * l_[k]; }
+    TZ_STAMP(PH_T1);
     tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM, 2>(nrp, sl, z0, red, rpar);
+    TZ_STAMP(PH_T2);
     const double mu = sl * pi.inv_mi;
     nrp *= tz_recip(red[13]);
     if (!(mu == mu) || !(nrp == nrp) || mu > 1e200) { status = 2; break; }
+    TZ_STAMP(PH_T3);
     const bool fresh_warm = (it == 0) && warm;     // a warm start may BEGIN below mu_floor: its first Newton step is what removes the residuals
     if ((nrp <= pi.tol_res && mu <= pi.mu_tol) || (mu <= pi.mu_floor && !fresh_warm)) {
-      exact_rd();
-      double e1 = 0, e2 = 0, e3 = 0;
-      for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
-      tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX, 1>(e1, e2, e3, red, rpar);
+      const double e1 = exact_rd(fresh_warm);
       const double nrd = e1 * tz_recip(red[12]);
       TZ_STAMP(PH_GEMVT);
       if (!(nrd == nrd)) { status = 2; break; }
@@ -1514,12 +1538,13 @@ retry_solve:
         F.fin.xbar[(size_t)b * (N + 1) * n + r] = a;
       }
     }
-    if (wave0) {                                         // xbar[1], the next nominal state: one wave, the sums folded across its lanes
-      for (int i = 0; i < n; ++i) {
-        double a = (t < n) ? cPhi[i * n + t] * x0[t] : 0.0;
-        for (int c = t; c < nv; c += 64) a += cGam[i * nv + c] * dxv[c];
+    {                                                    // xbar[1], the next nominal state: component i by wave i mod 4, the sums folded across its lanes
+      const int ln = t & 63;
+      for (int i = __builtin_amdgcn_readfirstlane(t >> 6); i < n; i += TZ_NWAVES) {
+        double a = (ln < n) ? cPhi[i * n + ln] * x0[ln] : 0.0;
+        for (int c = ln; c < nv; c += 64) a += cGam[i * nv + c] * dxv[c];
         a = tz_wave_reduce<RED_SUM>(a);
-        if (t == i) tmpz[i] = a;
+        if (ln == 0) tmpz[i] = a;
       }
     }
     __syncthreads();

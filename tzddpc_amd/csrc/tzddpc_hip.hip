@@ -336,7 +336,10 @@ int launch_solve(tz_problem* p, int B, const double* d_xbar0, const double* d_e0
   {
     Timer tm(p, K_IPM);
     IpmParams ip = ipm_params(p, B, d_status, d_iters, warm, track_prev);
-    if (d_active) { ip.mu_tol *= 1e-3; ip.mu_floor *= 1e-3; }     // active-set readout (slack < multiplier) needs the complementarity products well below the slacks
+    // active-set readout (slack < multiplier) needs the complementarity products well below the slacks: three decades below the
+    // stopping target, but never below 1e-6 tol (1e-16 at the default tolerance: what the loosest calibrated target used to give --
+    // with the tighter targets of round 3 an unbounded 1e-3 asked degenerate problems for mu = 1e-18 and they ended TZ_NUMERICAL)
+    if (d_active) { const double f = std::min(1.0, std::max(1e-3, 1e-6 * p->tol / ip.mu_tol)); ip.mu_tol *= f; ip.mu_floor *= f; }
     hipLaunchKernelGGL(p->ipm_fn, dim3(B), dim3(TZ_THREADS), p->lds_bytes, st, ip);
   }
   {
@@ -592,7 +595,11 @@ static int gs_eval(tz_genstack* g, int B, const double* de0, const double* dz, d
     // many: 256 per workgroup, the stack is re-read from L2 by the tiles of a chunk, which share an XCD
     const bool split = B <= 64;
     const int nq = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
-    nsub = split ? std::min(TZ_GS_MAXSUB, std::max(1, (2048 + g->nchunk - 1) / g->nchunk)) : 1;   // >= ~2000 blocks for the chip to balance
+    nsub = split ? 2 : 1;                             // two blocks per chunk when every block streams its tiles once (measured at 32 trajectories,
+    if (split) {                                      // 636 chunks: 1 -> 0.0670 ms, 2 -> 0.0641 ms, 4 -> 0.120 ms: the un-overlapped prologue of short blocks)
+      const char* e = getenv("TZ_GS_NSUB");
+      if (e) nsub = std::min(TZ_GS_MAXSUB, std::max(1, atoi(e)));
+    }
     const int ntt = split ? nsub : (B + 255) / 256;
     GenstackMParams qm{B, n, m, g->N, g->nchunk, ntt, nsub, g->recs_mf.p, g->chunks_m.p, de0, dz, g->partial.p};
     const dim3 gm((unsigned)(((g->nchunk + 7) / 8) * 8 * ntt));

@@ -229,33 +229,51 @@ class TZDDPC(object):
         Xi, Ui = self.zonotopes.X.interval, self.zonotopes.U.interval
         W = self.zonotopes.W
         stack = None
+        cuts = None
         epigraph = str(solver_kwargs.pop("epigraph", "auto"))
+        dense = str(solver_kwargs.pop("dense", "auto"))         # dense generators: "literal" | "cuts" | "auto" (literal while it fits)
         if DK is None or Dd is None:
             # dense generators (reduce(order > 1), or no reduction): no collapse -- the LITERAL problem, one epigraph variable per
-            # decision-dependent generator entry; feasible while it fits the LDS-resident Newton system (<= 256 variables)
+            # decision-dependent generator entry, while it fits the LDS-resident Newton system (<= 256 variables); beyond that its
+            # CUTTING-PLANE form: the same feasible set described by sign-pattern rows that are added as the literal evaluation of the
+            # solutions (K1g, on the device) shows them violated -- N m + (loss epigraphs) variables whatever the generator count
             from .genstack import build_stack, count_generators
             tot, dec = count_generators(self.MdataK.num_generators, self.Mdelta.num_generators, W.num_generators, int(horizon), k0,
                                         nseg=int(horizon))
-            if sum(dec) * (n + m) > 8 * TZ_MAX_VARIABLES or sum(tot) > 4_000_000:
+            if dense not in ("auto", "literal", "cuts"):
+                raise ValueError(f"dense={dense!r}")
+            if sum(tot) > 4_000_000:
+                raise StructureError(
+                    f"MdataK / Mdelta have dense generators and the tubes of the literal problem hold {sum(tot)} generators (they grow by "
+                    "gamma_K + 1 per product): use the Girard order-1 boxes of build_zonotopes_theta (reference tzddpc/tzddpc.py:126-128), "
+                    "a shorter horizon or build_problem_simplified with a small k0")
+            if dense == "literal" and sum(dec) * (n + m) > 8 * TZ_MAX_VARIABLES:
                 raise StructureError(
                     f"MdataK / Mdelta have dense generators and the literal problem needs up to {sum(dec) * (n + m)} epigraph variables "
-                    f"({sum(tot)} generators in the tubes); the device solver holds {TZ_MAX_VARIABLES} variables.  Use the Girard order-1 "
-                    "boxes of build_zonotopes_theta (reference tzddpc/tzddpc.py:126-128), a shorter horizon or a smaller k0")
+                    f"({sum(tot)} generators in the tubes); the device solver holds {TZ_MAX_VARIABLES}: build with dense=\"cuts\" (or \"auto\")")
             stack = build_stack(self.MdataK, self.Mdelta, self.theta.K, W, n, m, int(horizon), k0, nseg=int(horizon))
             ndec = int(np.count_nonzero(stack.src > 0)) * (n + m)
-            if ndec + int(horizon) * m > 4 * TZ_MAX_VARIABLES:
+            if dense == "cuts" or (dense == "auto" and ndec + int(horizon) * m > TZ_MAX_VARIABLES):
+                cuts = {}
+            elif ndec + int(horizon) * m > 4 * TZ_MAX_VARIABLES:
                 raise StructureError(
-                    f"MdataK / Mdelta have dense generators and the literal problem needs about {ndec + int(horizon) * m} variables "
-                    f"(one per decision-dependent generator entry); the device solver holds {TZ_MAX_VARIABLES}.  Use the Girard order-1 "
-                    "boxes of build_zonotopes_theta (reference tzddpc/tzddpc.py:126-128), a shorter horizon or a smaller k0")
+                    f"MdataK / Mdelta have dense generators and the literal problem needs about {ndec + int(horizon) * m} variables (one "
+                    f"per decision-dependent generator entry); the device solver holds {TZ_MAX_VARIABLES}: build with dense=\"cuts\" (or \"auto\")")
         qp = build_parametric_qp(A, B, self.MdataK.center, DK, Dd, self.theta.K, W.center, W.generators,
                                  Xi.left_limit, Xi.right_limit, Ui.left_limit, Ui.right_limit,
-                                 int(horizon), build_loss, build_constraints, k0, epigraph=epigraph, literal=stack)
+                                 int(horizon), build_loss, build_constraints, k0, epigraph=epigraph, literal=stack, cuts=cuts)
         if stack is not None and qp.nz > TZ_MAX_VARIABLES:
             raise StructureError(
                 f"MdataK / Mdelta have dense generators and the literal problem has {qp.nz} variables (one per decision-dependent "
-                f"generator entry); the device solver holds {TZ_MAX_VARIABLES}.  Use the Girard order-1 boxes of build_zonotopes_theta "
-                "(reference tzddpc/tzddpc.py:126-128), a shorter horizon or a smaller k0")
+                f"generator entry); the device solver holds {TZ_MAX_VARIABLES}: build with dense=\"cuts\" (cutting-plane form), or use the "
+                "Girard order-1 boxes of build_zonotopes_theta (reference tzddpc/tzddpc.py:126-128), a shorter horizon or a smaller k0")
+        self._cuts = cuts
+        self._cut_args = None
+        if cuts is not None:                              # what a rebuild with more cuts needs
+            self._cut_args = dict(args=(A, B, self.MdataK.center, DK, Dd, self.theta.K, W.center, W.generators, Xi.left_limit, Xi.right_limit,
+                                        Ui.left_limit, Ui.right_limit, int(horizon), build_loss, build_constraints, k0),
+                                  stack=stack, solver_kwargs=dict(solver_kwargs))
+            solver_kwargs.setdefault("calibrate", False)  # the problem changes as cuts arrive: no build-time closed loops on it
         self.qp = qp
         self.horizon = int(horizon)
         self.k0 = k0
@@ -271,6 +289,8 @@ class TZDDPC(object):
         if stack is not None:                           # decision-independent generators: evaluated per solve on the device (K1g)
             self._gs_tube = native.GenStack(self.device, qp.estack)
             self._native.attach_tube_stack(self._gs_tube)
+        if cuts is not None:                            # the whole stack: separation oracle of the cutting-plane loop (literal_tubes)
+            self._gs_full = ((int(horizon), k0), native.GenStack(self.device, stack))
         # plant of the calibration loops: the identified centre (a sampled member of the boxed Mdata was tried: its mismatch is far
         # larger than a real plant's and turned the preference around on the double integrators)
         # the two warm-start knobs are calibrated at the tightest complementarity target, then the target is relaxed as far as
@@ -463,8 +483,11 @@ class TZDDPC(object):
         """One MPC step for one trajectory; keyword arguments (``verbose=...``) are accepted and ignored."""
         if self._native is None:
             raise Exception("Problem was not built: call build_problem first")
-        v, xbar, cost, status, iters, _ = self._native.solve_batch(np.asarray(xbar0, float).reshape(1, -1),
-                                                                  np.asarray(e0, float).reshape(1, -1))
+        if getattr(self, "_cuts", None) is not None:
+            v, xbar, cost, status, iters, _ = self._solve_with_cuts(np.asarray(xbar0, float).reshape(1, -1), np.asarray(e0, float).reshape(1, -1), False)
+        else:
+            v, xbar, cost, status, iters, _ = self._native.solve_batch(np.asarray(xbar0, float).reshape(1, -1),
+                                                                      np.asarray(e0, float).reshape(1, -1))
         st = int(status[0])
         self.last_status, self.last_iters = st, int(iters[0])
         if st in (native.TZ_MAX_ITER, native.TZ_NUMERICAL):
@@ -593,7 +616,10 @@ class TZDDPC(object):
         ``ze1`` (B, n, 1 + Gamma_1) is the 4th return value of the reference's ``solve`` (``:377``) for every trajectory."""
         if self._native is None:
             raise Exception("Problem was not built: call build_problem first")
-        v, xbar, cost, status, iters, active = self._native.solve_batch(xbar0, e0, want_active)
+        if getattr(self, "_cuts", None) is not None:
+            v, xbar, cost, status, iters, active = self._solve_with_cuts(xbar0, e0, want_active)
+        else:
+            v, xbar, cost, status, iters, active = self._native.solve_batch(xbar0, e0, want_active)
         out = dict(cost=cost, v=v, xbar=xbar, status=status, iters=iters)
         if want_active:
             if getattr(self, "_elim", None) is not None:
@@ -607,5 +633,106 @@ class TZDDPC(object):
         """Closed loop of ``examples/1.double_integrator_sim.py:75-90`` for B trajectories, T = noise.shape[1] steps."""
         if self._native is None:
             raise Exception("Problem was not built: call build_problem first")
+        if getattr(self, "_cuts", None) is not None:
+            return self._simulate_with_cuts(x0, noise, A_true, B_true)
         x, u, cost, status = self._native.simulate_batch(x0, noise, A_true, B_true)
         return dict(x=x, u=u, cost=cost, status=status)
+
+    # ---- dense generators beyond the literal problem: cutting planes (K1g is the separation oracle) ---------------------------
+    def _solve_with_cuts(self, xbar0, e0, want_active=False, tol=1e-9, max_rounds=40, per_family=4):
+        """The literal problem (reference ``tzddpc/tzddpc.py:172-207`` / ``:283-324`` with dense generators) by cutting planes: solve
+        the relaxation that holds the sign-pattern rows found so far (device), evaluate the literal tubes of every solution (device,
+        K1g over the whole stack), and for every tube row that the true radius violates add the pattern sigma_g = sign(a_g) of that
+        trajectory's generator values (device, ``tz_genstack_values``) -- a row that is valid for ALL parameter values, so it joins
+        the shared constraint matrix; repeat until no row is violated by more than `tol`.  A solution of the relaxation that is
+        feasible for the literal problem is optimal for it.  The cuts stay with the controller: later solves start from them."""
+        n, m, N = self.dim_x, self.dim_u, self.horizon
+        xbar0 = np.asarray(xbar0, float).reshape(-1, n); e0 = np.asarray(e0, float).reshape(-1, n)
+        Xi, Ui = self.zonotopes.X.interval, self.zonotopes.U.interval
+        xl, xu = np.asarray(Xi.left_limit, float), np.asarray(Xi.right_limit, float)
+        ul, uu = np.asarray(Ui.left_limit, float), np.asarray(Ui.right_limit, float)
+        K = np.atleast_2d(np.asarray(self.theta.K, float))
+        stack = self._cut_args["stack"]
+        gs = self._gs_full[1]
+        self.cut_rounds = 0
+        while True:
+            v, xbar, cost, status, iters, active = self._native.solve_batch(xbar0, e0, want_active)
+            ok = np.nonzero(status == 0)[0]
+            if ok.size == 0 or self.cut_rounds >= max_rounds:
+                break
+            tb = self.literal_tubes(e0[ok], xbar[ok], v[ok])
+            cx = xbar[ok][:, :N] + tb["center"]                                   # (Ze[k] + xbar[k]).interval  (:191)
+            cu = v[ok] + np.einsum("ji,bki->bkj", K, tb["center"])                 # (Ze[k] K + v[k]).interval    (:192)
+            sx = 1.0 + np.maximum(np.abs(xl), np.abs(xu)); su = 1.0 + np.maximum(np.abs(ul), np.abs(uu))
+            vx = np.maximum(cx + tb["rad_x"] - xu, xl - (cx - tb["rad_x"])) / sx   # (B, N, n) violation of the pair of rows, relative
+            vu = np.maximum(cu + tb["rad_u"] - uu, ul - (cu - tb["rad_u"])) / su
+            bad_x, bad_u = vx > tol, vu > tol
+            if not (bad_x.any() or bad_u.any()):
+                break
+            zeta = np.concatenate([xbar[ok][:, :N], v[ok]], axis=2)
+            added = 0
+            for k in np.nonzero(bad_x.any(axis=(0, 2)) | bad_u.any(axis=(0, 2)))[0]:
+                sel = np.nonzero(bad_x[:, k].any(axis=1) | bad_u[:, k].any(axis=1))[0]
+                Z = gs.values(int(k), e0[ok][sel], zeta[sel])[:, :, 1:]             # generator columns of Ze[k]: (sel, n, ngen_k)
+                KZ = np.einsum("ji,big->bjg", K, Z)
+                g0 = int(stack.seg_ptr[k])
+                for kind, comps, vals, bad in (("x", n, Z, bad_x), ("u", m, KZ, bad_u)):
+                    for i in range(comps):
+                        fam = self.qp.families.get((int(k), kind, i))
+                        if not fam:
+                            continue
+                        rows = np.nonzero(bad[sel, k, i])[0]
+                        if rows.size == 0:
+                            continue
+                        cols = np.asarray(fam, int) - g0
+                        pats = np.where(vals[rows][:, i, :][:, cols] >= 0.0, 1.0, -1.0)
+                        have = {p.tobytes() for p in self._cuts.get((int(k), kind, i), [])}
+                        uniq, cnt = np.unique(pats, axis=0, return_counts=True)
+                        for p in uniq[np.argsort(-cnt)][:per_family]:                  # the most frequent new patterns first
+                            if p.tobytes() not in have:
+                                self._cuts.setdefault((int(k), kind, i), []).append(p.copy()); have.add(p.tobytes()); added += 1
+            if added == 0:
+                break                                                                  # nothing new to add: violations are below what the patterns resolve
+            self._rebuild_with_cuts()
+            self.cut_rounds += 1
+        return v, xbar, cost, status, iters, active
+
+    def _rebuild_with_cuts(self):
+        ca = self._cut_args
+        qp = build_parametric_qp(*ca["args"], literal=ca["stack"], cuts=self._cuts)
+        if 2 * qp.nc > 6 * 256:
+            raise StructureError(f"the cutting-plane form has grown to {qp.nc} two-sided rows; the device solver holds 1536 one-sided rows")
+        self.qp = qp
+        self._native.close()
+        self._native, info = self._native_from_qp(qp, dict(ca["solver_kwargs"]))
+        self._elim, self._scal, self._row_of = info["elim"], info["scal"], info["row_of"]
+        self._native.attach_tube_stack(self._gs_tube)
+        self._native.set_warm_shift(0)
+        self.problem_full = self.optimization_problem = self._native
+
+    def num_cuts(self) -> int:
+        return 0 if getattr(self, "_cuts", None) is None else int(sum(len(v) for v in self._cuts.values()))
+
+    def _simulate_with_cuts(self, x0, noise, A_true, B_true):
+        """Closed loop of ``examples/1.double_integrator_sim.py:75-90`` for a cutting-plane problem: one verified ``solve_batch`` per
+        step (the separation has to sit between the solve and the plant update, so the steps are separate launches; the plant and
+        error updates of the example's loop -- three small matrix products per step -- are done here, as in the example)."""
+        n, m = self.dim_x, self.dim_u
+        x = np.asarray(x0, float).reshape(-1, n).copy(); Bn = x.shape[0]
+        noise = np.asarray(noise, float).reshape(Bn, -1, n); T = noise.shape[1]
+        A_true = np.asarray(A_true, float); B_true = np.asarray(B_true, float).reshape(n, m)
+        K = np.atleast_2d(np.asarray(self.theta.K, float))
+        xs = np.empty((Bn, T + 1, n)); us = np.empty((Bn, T, m)); cs = np.empty((Bn, T)); sticky = np.zeros(Bn, dtype=np.int32)
+        xbar = x.copy(); e = np.zeros_like(x); xs[:, 0] = x
+        Phi1 = self.qp.Phi.reshape(self.horizon + 1, n, n)[1]
+        for t in range(T):
+            v, xb, cost, status, _, _ = self._solve_with_cuts(xbar, e)
+            okb = status == 0
+            v0 = np.where(okb[:, None], v[:, 0], 0.0)                              # failed step: v = 0 (u = K e), nominal state follows Phi
+            nxt = np.where(okb[:, None], xb[:, 1], xbar @ Phi1.T)
+            u = e @ K.T + v0                                                        # :84
+            x = x @ A_true.T + u @ B_true.T + noise[:, t]                           # :85
+            xbar = nxt; e = x - xbar                                                # :83, :87
+            xs[:, t + 1] = x; us[:, t] = u; cs[:, t] = np.where(okb, cost, np.inf)
+            sticky = np.where((sticky == 0) & ~okb, status, sticky)
+        return dict(x=xs, u=us, cost=cs, status=sticky)
