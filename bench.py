@@ -354,11 +354,19 @@ def bench_genstack(args, local_rank=0):
     hbm_bound = gbs / 8000.0 > tfs / F64_MFMA_PEAK_TFLOPS
     roof = ({"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0} if hbm_bound else
             {"bound": "mfma", "achieved": tfs, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / F64_MFMA_PEAK_TFLOPS})
-    roof.update({"traffic": None, "kernel": "tz_genstack_kernel", "avg_launch_ms": med, "launches": len(ms),
+    traffic = tsrc = None
+    try:                                                      # HBM-side bytes of one launch from the PMC passes archived under profiles/
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))["configs"][f"{args.config}_b{B}"]
+        if N == GENSTACK_CONFIGS[args.config][1] and k0 == GENSTACK_CONFIGS[args.config][2]:
+            traffic, tsrc = float(e["fetch_bytes_per_launch"]) + float(e["write_bytes_per_launch"]), e["source"]
+    except Exception:
+        pass
+    roof.update({"traffic": traffic, "traffic_source": tsrc, "kernel": "tz_genstack_mfma_kernel" if 3 <= n + m <= 7 else "tz_genstack_kernel", "avg_launch_ms": med, "launches": len(ms),
                  "algorithmic_bytes_per_launch": bytes_alg, "algorithmic_flop_per_launch": flop,
                  "other_roof": {"hbm_frac": gbs / 8000.0, "f64_frac": tfs / F64_MFMA_PEAK_TFLOPS},
-                 "note": "the stack is read once per tile of 256 trajectories (8 n (1 + n + m) bytes per generator and tile); 2 n (n + m) + 2 n + 2 m n + n + m "
-                         "f64 flop per generator and trajectory on the vector / matrix f64 pipe (same 78.6 TFLOP/s peak); the larger of the two fractions binds"})
+                 "note": "algorithmic bytes: the stack once per tile of 256 trajectories at 8 n (1 + n + m) bytes per generator (the kernel's own layout carries "
+                         "the m rows K M as well: (n + m)(1 + n + m) doubles per generator, +20 % for n = 5, m = 1); algorithmic flop: 2 n (n + m) + 2 n + 2 m n + n + m "
+                         "f64 flop per generator and trajectory against the 78.6 TFLOP/s f64 matrix (= vector) peak; the larger of the two fractions binds"})
     print(json.dumps({"metric": f"literal tube evaluations/s (K1g), {args.config}", "value": B * args.steps / elapsed, "unit": "trajectory tube-stack evaluations/s",
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
