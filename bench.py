@@ -148,10 +148,11 @@ def cpu_baseline(ctl, A, B, zon, label, warmup, steps, seconds_budget=24.0, repe
 
     timed(cores, T, cores)                                                       # page in, spin the thread pool up
     dt, _ = timed(cores, T, cores)                                               # calibration: one trajectory per thread
-    per = 0.55 * seconds_budget / max(repeats, 1)                                # seconds per repeat (all + warm-up legs)
+    per = 0.55 * seconds_budget / (max(repeats, 1) + 1)                          # seconds per sample (all + warm-up legs), one of them discarded
     traj = int(max(cores, min(16384, cores * max(1, int(per / max(dt * (1.0 + warmup / T), 1e-9))))))
     samples, ok = [], True
-    for _ in range(max(repeats, 1)):
+    rate(traj, cores)                                                            # one discarded sample: the first full-size run on a box is 1.5-2x slower
+    for _ in range(max(repeats, 1)):                                             # (thread pool, clocks, page faults of the work areas)
         v, _, out = rate(traj, cores)
         samples.append(v); ok = ok and bool((out["status"] == 0).all())
     # one thread, for scale (SURVEY section 8d asks for both): a sample of >= ~1 s

@@ -7,7 +7,7 @@ tag=${1:-rXX}; cfg=${2:-di_n20}; steps=${3:-20}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out; t=${tag}_${cfg}
 python3 bench.py --config $cfg --steps $steps --warmup 5 > $out/${t}_bench.json 2> $out/${t}_bench.err || exit 1
-B="python3 bench.py --config $cfg --steps $steps --warmup 5 --repeats 1 --no-cpu-baseline"
+B="python3 bench.py --config $cfg --steps $steps --warmup 5 --repeats 1 --no-cpu-baseline --full-run-steps 0"   # no full-run / jitter legs: the timed window is the LAST launch
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${t}_trace -o t -- $B > $out/${t}_trace.log 2>&1 || exit 1
 cp $(find $out/${t}_trace -name "*kernel_stats.csv" | head -1) $out/${t}_kernel_stats.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do

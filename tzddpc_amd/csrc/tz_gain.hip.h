@@ -37,11 +37,18 @@ __device__ inline void tz_gain_accumulate(const GainParams& q, double* tile, int
     __syncthreads();
     for (int i = t; i < ng * n2; i += blockDim.x) tile[i] = q.H[(size_t)g0 * n2 + i];
     __syncthreads();
-    for (int g = 0; g < ng; ++g) {
-      const double b = live ? q.beta_in[(size_t)s * q.ngen + g0 + g] : 0.0;
-      const double* h = tile + g * n2;
+    // this lane's coefficients of the tile: requested together (a lane's row of beta is contiguous), not one dependent 8-byte load
+    // per generator -- round 2's version spent its time in those round trips (profiles/r3j_aux_kernel_stats.csv)
+    double bt[TZ_GN_TILE];
 #pragma unroll
-      for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) if (e < n2) M[e] += b * h[e];
+    for (int g = 0; g < TZ_GN_TILE; ++g) bt[g] = (live && g < ng) ? q.beta_in[(size_t)s * q.ngen + g0 + g] : 0.0;
+#pragma unroll
+    for (int g = 0; g < TZ_GN_TILE; ++g) {
+      if (g < ng) {
+        const double* h = tile + g * n2;
+#pragma unroll
+        for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) if (e < n2) M[e] += bt[g] * h[e];
+      }
     }
   }
 }
@@ -191,18 +198,28 @@ __global__ __launch_bounds__(64) void tz_adversary_kernel(GainParams q) {
       __syncthreads();
       for (int i = lane; i < ng * n2; i += 64) tile[i] = q.H[(size_t)g0 * n2 + i];
       __syncthreads();
-      for (int g = 0; g < ng; ++g) {
-        const double* h = tile + g * n2;
-        double d = 0.0;
+      double bt[TZ_GN_TILE];                             // this lane's coefficients of the tile: loaded together, stored back together
 #pragma unroll
-        for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) if (e < n2) d += slab[(e << 6) + lane] * h[e];
-        double b = live ? q.beta_out[(size_t)s * q.ngen + g0 + g] : 0.0;
-        if (moving) {
-          const double nb = (d > 0.0) ? 1.0 : ((d < 0.0) ? -1.0 : b);     // vertex of the box maximising the linearisation
-          if (nb != b) { changed = true; b = nb; q.beta_out[(size_t)s * q.ngen + g0 + g] = nb; }
+      for (int g = 0; g < TZ_GN_TILE; ++g) bt[g] = (live && g < ng) ? q.beta_out[(size_t)s * q.ngen + g0 + g] : 0.0;
+#pragma unroll
+      for (int g = 0; g < TZ_GN_TILE; ++g) {
+        if (g < ng) {
+          const double* h = tile + g * n2;
+          double d = 0.0;
+#pragma unroll
+          for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) if (e < n2) d += slab[(e << 6) + lane] * h[e];
+          double b = bt[g];
+          if (moving) {
+            const double nb = (d > 0.0) ? 1.0 : ((d < 0.0) ? -1.0 : b);     // vertex of the box maximising the linearisation
+            if (nb != b) { changed = true; b = nb; bt[g] = nb; }
+          }
+#pragma unroll
+          for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) if (e < n2) M[e] += b * h[e];
         }
+      }
+      if (moving) {
 #pragma unroll
-        for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) if (e < n2) M[e] += b * h[e];
+        for (int g = 0; g < TZ_GN_TILE; ++g) if (g < ng) q.beta_out[(size_t)s * q.ngen + g0 + g] = bt[g];
       }
     }
     if (moving) ++steps;
