@@ -478,11 +478,12 @@ def main(argv=None):
             run(warm, k)
             out["gathered"] = collect()                                      # per-trajectory cost + final state only
             torch.cuda.synchronize()
-            mine = time.perf_counter() - t0
+            mine = time.perf_counter() - t0                                  # this rank's K steps + gather, device idle again
             if use_dist:
-                dist.barrier()
-            elapsed = time.perf_counter() - t0
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                dist.barrier()                                               # the closing barrier of the bracket: no rank starts the next window early
+            # the job's time is the MAX over ranks of their own bracketed times (the clock is read before the closing barrier: its own
+            # latency -- an RCCL launch, 60 us against a 0.7 ms window -- is not part of the K steps)
+            tmax = torch.tensor([mine], dtype=torch.float64, device=dev)
             if use_dist:
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 tl = torch.zeros(world, dtype=torch.float64, device=dev)
