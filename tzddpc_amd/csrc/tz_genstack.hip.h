@@ -19,6 +19,10 @@
 
 #define TZ_GS_TILE 64            // generators per LDS tile
 #define TZ_GS_CHUNK 1024         // generators per workgroup (host plan)
+#ifndef TZ_GS_GWDIV
+#define TZ_GS_GWDIV 16           // narrow kernel: a wave tile is 1 / TZ_GS_GWDIV of the shared tile; smaller tiles = fewer registers and less LDS = more
+                                 // waves per SIMD to cover the LDS latency of the A reads (32 trajectories: 4 -> 0.0624 ms, 8 -> 0.0592, 16 -> 0.0587)
+#endif
 #define TZ_GS_MAXSUB 8           // matrix-core kernel, few trajectories: at most this many blocks share a chunk
 
 struct GsChunk { int seg, src, g0, g1; };        // generators [g0, g1) of the SORTED stack: tube seg, source src (-1 none, 0 e0, 1 + j zeta_j)
@@ -277,6 +281,134 @@ __global__ __launch_bounds__(256) void tz_genstack_mfma_kernel(GenstackMParams q
       if (b < q.B) {
 #pragma unroll
         for (int c = 0; c < P; ++c) q.partial[((size_t)(chunk * q.nsub + sub) * q.B + b) * P + c] = acc[c][qq];
+      }
+    }
+  }
+}
+
+// Few trajectories (<= 64), wave-private pipeline: every wave streams ITS tiles (GW = GT / 4 groups each, dealt round-robin to the
+// four waves) through its own double buffer in LDS -- global -> registers -> LDS -> A operands -- with wave-level ordering only: no
+// workgroup barrier inside the stream, so one wave's loads, another's LDS writes and a third's matrix instructions overlap instead
+// of meeting at a barrier per tile (the SPLIT form of tz_genstack_mfma_kernel: MFMA pipe 44 % busy, HBM at half its achievable rate,
+// neither saturated).  Same arithmetic per wave as there; the four waves' sums meet in LDS in wave order at the end.
+template <int P, int NQ>
+__global__ __launch_bounds__(256) void tz_genstack_mfma_narrow_kernel(GenstackMParams q) {
+  constexpr int KS = (P + 3) / 4, GD = GsTile<P>::GD, GW = (GsTile<P>::GT >= TZ_GS_GWDIV) ? GsTile<P>::GT / TZ_GS_GWDIV : 1;
+  constexpr int WD2 = GW * GD / 2, LDW = (WD2 + 63) / 64;
+  __shared__ double2 wtile[4][2][WD2 + 2];
+  __shared__ double xred[3 * P * NQ * 16];
+  const int bid = blockIdx.x;
+  const int cgrp = bid / (8 * q.ntt), rem = bid % (8 * q.ntt);
+  const int chunk = cgrp * 8 + (rem & 7), sub = rem >> 3;
+  if (chunk >= q.nchunk) return;
+  const GsChunkM ch = q.chunks[chunk];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double bx[KS][NQ];
+  {
+    const int k = lane >> 4, n = q.n, pc = q.n + q.m;
+    const int width = ch.src == 0 ? n : (ch.src > 0 ? pc : 0);
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+      const int b = 16 * qq + (lane & 15);
+      const double* sv = ch.src == 0 ? q.e0 + (size_t)b * n : q.zeta + ((size_t)b * q.N + (ch.src > 0 ? ch.src - 1 : 0)) * pc;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) bx[s][qq] = (b < q.B && 4 * s + k < width) ? sv[4 * s + k] : 0.0;
+    }
+  }
+  double acc[P][NQ];
+#pragma unroll
+  for (int c = 0; c < P; ++c)
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) acc[c][qq] = 0.0;
+  const double2* src2 = reinterpret_cast<const double2*>(q.recs + (size_t)ch.q0 * GD);
+  // wave tiles of this block: [t_lo, t_hi) of the chunk's ceil(nq / GW); this wave takes t_lo + wave, + 4, ...
+  const int nwt_all = (ch.nq + GW - 1) / GW;
+  const int t_lo = (int)(((long long)nwt_all * sub) / q.nsub), t_hi = (int)(((long long)nwt_all * (sub + 1)) / q.nsub);
+  const int mine = (t_hi - t_lo - wave + 3) / 4;                 // number of tiles of this wave (<= 0: none)
+  double2 stA[LDW], stB[LDW];
+  auto fetch = [&](double2 (&stage)[LDW], int j) {
+    const int tg = t_lo + wave + 4 * j;
+    const int nd2 = min(GW, ch.nq - tg * GW) * (GD / 2);
+    const double2* s = src2 + (size_t)tg * WD2;
+#pragma unroll
+    for (int i = 0; i < LDW; ++i) { const int e = lane + 64 * i; stage[i] = (e < nd2) ? s[e] : make_double2(0.0, 0.0); }
+  };
+  auto park = [&](const double2 (&stage)[LDW], int buf) {
+#pragma unroll
+    for (int i = 0; i < LDW; ++i) { const int e = lane + 64 * i; if (e < WD2) wtile[wave][buf][e] = stage[i]; }
+  };
+  auto wsync = [&]() {                                           // this wave's LDS writes before its later reads (and the reverse)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const int ai = (lane & 3) * P + (lane >> 4), ci = 4 * P * P + (lane >> 4);
+  auto products = [&](int j) {
+    const double* buf = reinterpret_cast<const double*>(wtile[wave][j & 1]);
+    const int ng = min(GW, ch.nq - (t_lo + wave + 4 * j) * GW);
+    for (int g = 0; g < ng; ++g) {
+      const double* gb = buf + g * GD;
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        const double m0v = gb[ci + 4 * c];
+        double d[NQ];
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) d[qq] = m0v;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const double a = gb[c * 4 * P + ai + 4 * s];
+#pragma unroll
+          for (int qq = 0; qq < NQ; ++qq) d[qq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bx[s][qq], d[qq], 0, 0, 0);
+        }
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) acc[c][qq] += fabs(d[qq]);
+      }
+    }
+  };
+  if (lane < 2) { wtile[wave][0][WD2 + lane] = make_double2(0.0, 0.0); wtile[wave][1][WD2 + lane] = make_double2(0.0, 0.0); }
+  if (mine > 0) {
+    fetch(stA, 0);
+    if (mine > 1) fetch(stB, 1);
+    park(stA, 0);
+    wsync();
+    for (int j = 0; j < mine; j += 2) {
+      if (j + 2 < mine) fetch(stA, j + 2);
+      products(j);
+      if (j + 1 < mine) park(stB, 1);
+      wsync();
+      if (j + 1 < mine) {
+        if (j + 3 < mine) fetch(stB, j + 3);
+        products(j + 1);
+        if (j + 2 < mine) park(stA, 0);
+        wsync();
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < P; ++c)
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+      double v = acc[c][qq];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      acc[c][qq] = v;
+    }
+  if (wave > 0 && lane < 16) {
+#pragma unroll
+    for (int c = 0; c < P; ++c)
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) xred[(((wave - 1) * P + c) * NQ + qq) * 16 + lane] = acc[c][qq];
+  }
+  __syncthreads();
+  if (wave == 0 && lane < 16) {
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+      const int b = 16 * qq + lane;
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        double v = acc[c][qq];
+        for (int w = 0; w < 3; ++w) v += xred[((w * P + c) * NQ + qq) * 16 + lane];
+        if (b < q.B) q.partial[((size_t)(chunk * q.nsub + sub) * q.B + b) * P + c] = v;
       }
     }
   }

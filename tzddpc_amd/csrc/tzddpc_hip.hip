@@ -603,8 +603,12 @@ static int gs_eval(tz_genstack* g, int B, const double* de0, const double* dz, d
     const int ntt = split ? nsub : (B + 255) / 256;
     GenstackMParams qm{B, n, m, g->N, g->nchunk, ntt, nsub, g->recs_mf.p, g->chunks_m.p, de0, dz, g->partial.p};
     const dim3 gm((unsigned)(((g->nchunk + 7) / 8) * 8 * ntt));
+    const bool narrow = split && !getenv("TZ_GS_NO_NARROW");     // wave-private pipeline (no barrier in the stream); the switch keeps the barrier form
 #define TZ_GS_LAUNCH(PP) do { \
       if (!split) hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 4, false>), gm, dim3(256), 0, st, qm); \
+      else if (narrow && nq == 1) hipLaunchKernelGGL((tz_genstack_mfma_narrow_kernel<PP, 1>), gm, dim3(256), 0, st, qm); \
+      else if (narrow && nq == 2) hipLaunchKernelGGL((tz_genstack_mfma_narrow_kernel<PP, 2>), gm, dim3(256), 0, st, qm); \
+      else if (narrow) hipLaunchKernelGGL((tz_genstack_mfma_narrow_kernel<PP, 4>), gm, dim3(256), 0, st, qm); \
       else if (nq == 1) hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 1, true>), gm, dim3(256), 0, st, qm); \
       else if (nq == 2) hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 2, true>), gm, dim3(256), 0, st, qm); \
       else hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 4, true>), gm, dim3(256), 0, st, qm); } while (0)
