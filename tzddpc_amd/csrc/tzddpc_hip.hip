@@ -431,7 +431,7 @@ static int gain_batch(bool adversary, int device, int32_t S, int32_t n, int32_t 
   if (adversary) TZ_HIP(dbout.alloc(std::max<size_t>(s * g, 1)));
   GainParams q{S, n, ngen, max_iter, dM0.p, dH.p, dbeta.p, adversary ? dbout.p : nullptr, dval.p, daux.p};
   const dim3 grid((S + 63) / 64), block(64);
-  if (adversary) hipLaunchKernelGGL(tz_adversary_kernel, grid, block, 0, 0, q);
+  if (adversary) hipLaunchKernelGGL(tz_adversary_kernel, dim3(S), dim3(256), 0, 0, q);          // one workgroup per starting point, lane = generator
   else hipLaunchKernelGGL(tz_specrad_kernel, grid, block, 0, 0, q);
   TZ_HIP(hipGetLastError());
   TZ_HIP(hipMemcpy(val, dval.p, s * sizeof(double), hipMemcpyDeviceToHost));
