@@ -14,6 +14,9 @@ struct dim3x { int x; };
 static dim3x threadIdx, blockIdx, blockDim;
 static void __syncthreads() {}
 static bool __any(bool b) { return b; }
+static int __syncthreads_or(int v) { return v; }
+enum { RED_SUM = 0 };
+template <int OP> static double tz_wave_reduce(double v) { return v; }      // (the adversary kernel is compiled, never run, on the host)
 #include "../../tzddpc_amd/csrc/tz_gain.hip.h"
 
 extern "C" int specrad_host(int S, int n, const double* Ms, double* rho) {
