@@ -204,7 +204,7 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
              sum_g |a_g(v, xbar0)| over its decision-dependent generators, is replaced by sum_g sigma_g a_g for every sign pattern
              sigma in cuts[(k, "x" | "u", i)] -- each one a valid inequality for every parameter value (sum sigma a <= sum |a|), so
              the rows are shared by all trajectories and steps like the rest of G; the caller adds the patterns that the literal
-             evaluation of a solution shows to be violated until none is (`TZDDPC` does, with K1g as the separation oracle).  The
+             evaluation of a solution shows to be violated until none is (`TZDDPC` does, with K1g as the separation routine).  The
              problem keeps N m + (loss epigraphs) variables whatever the generator count.  `ParametricQP.families` lists, per
              (k, kind, i), the generators of the row (indices into the tube's literal order) for the caller's sign look-up."""
     Ahat = np.asarray(Ahat, float); Bhat = np.asarray(Bhat, float)

@@ -289,7 +289,7 @@ class TZDDPC(object):
         if stack is not None:                           # decision-independent generators: evaluated per solve on the device (K1g)
             self._gs_tube = native.GenStack(self.device, qp.estack)
             self._native.attach_tube_stack(self._gs_tube)
-        if cuts is not None:                            # the whole stack: separation oracle of the cutting-plane loop (literal_tubes)
+        if cuts is not None:                            # the whole stack: what the cutting-plane loop separates with (literal_tubes)
             self._gs_full = ((int(horizon), k0), native.GenStack(self.device, stack))
         # plant of the calibration loops: the identified centre (a sampled member of the boxed Mdata was tried: its mismatch is far
         # larger than a real plant's and turned the preference around on the double integrators)
@@ -444,7 +444,7 @@ class TZDDPC(object):
         fewest factorisations from the sixth step on is kept (ties within 2 % go to the smaller push).  The cap is what makes the choice robust: the rows
         are equilibrated, violations of 5 ... 70 occur in the first steps of a transient and on any plant that differs from the
         model, and a push that large erases the slack information of the start; with the cap the settings that are best on the
-        identified centre are also (near) best on the example's true plant (C oracle, both plants: double integrator N=20
+        identified centre are also (near) best on the example's true plant (measured with the plain-C restatement under tests, both plants: double integrator N=20
         0.83 -> 0.46-0.51 factorisations per step in the driver window, N=40 0.95 -> 0.45-0.49)."""
         nat = self._native
         if mode == "auto" and os.environ.get("TZ_WARM_GAIN"):                     # experiment switch (tools/): same range as the setter
@@ -638,7 +638,7 @@ class TZDDPC(object):
         x, u, cost, status = self._native.simulate_batch(x0, noise, A_true, B_true)
         return dict(x=x, u=u, cost=cost, status=status)
 
-    # ---- dense generators beyond the literal problem: cutting planes (K1g is the separation oracle) ---------------------------
+    # ---- dense generators beyond the literal problem: cutting planes (K1g does the separation) -------------------------------
     def _solve_with_cuts(self, xbar0, e0, want_active=False, tol=1e-9, max_rounds=40, per_family=4):
         """The literal problem (reference ``tzddpc/tzddpc.py:172-207`` / ``:283-324`` with dense generators) by cutting planes: solve
         the relaxation that holds the sign-pattern rows found so far (device), evaluate the literal tubes of every solution (device,
