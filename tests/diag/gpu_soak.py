@@ -4,7 +4,8 @@ sys.path.insert(0, ".")
 from tests import common
 from oracle.c_oracle import COracle
 from tzddpc_amd.dist import vertex_noise
-for case, Bn, T in (("di_n20", 1024, 2000), ("pulley_n10", 1024, 1000), ("di_n40", 512, 600), ("dim5_n20", 512, 300), ("di_n5", 1024, 1000)):
+for case, Bn, T in (("di_n20", 1024, 2000), ("pulley_n10", 1024, 1000), ("di_n40", 512, 600), ("dim5_n20", 512, 300), ("di_n5", 1024, 1000),
+                    ("dim5m2q_n20", 256, 200), ("di2in_n10", 1024, 1000), ("dim5m2_n20", 128, 100)):      # round 3: two inputs
     ctl, (A, B, zon) = common.gpu_controller(case)
     noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
     x0 = np.tile(zon.X0.center, (Bn, 1))

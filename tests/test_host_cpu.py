@@ -288,3 +288,23 @@ def test_sharded_closed_loops_equal_the_unsharded_batch_gloo(built, tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script), root, port], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_bench_accepts_the_reference_harness_flags():
+    """bench.py carries the flags of the reference's complexity harness (examples/1.double_integrator_computation_complexity.py:179-189:
+    -m TZDDPC|STZDDPC|ZPC, -n evaluations, -ho horizon, -k0): parsing only (no GPU)."""
+    root = common.__file__.rsplit("/tests/", 1)[0]
+    sys.path.insert(0, root)
+    import bench
+    a = bench.parse_args(["-m", "STZDDPC", "-ho", "6", "-k0", "2", "-n", "3"])
+    assert a.config == "di_n20" and a.horizon == 6 and a.k0_override == 2 and a.repeats == 3
+    a = bench.parse_args(["-m", "TZDDPC"])
+    assert a.horizon == 3 and a.k0_override is None and a.repeats == 11           # the harness's default horizon; full problem
+    a = bench.parse_args([])
+    assert a.config == "di_n20" and a.k0_override == "keep" and a.gpus == 1 and a.horizon == 0
+    a = bench.parse_args(["--config", "genstack_dim5_k1", "--batch", "32"])
+    assert a.config in bench.GENSTACK_CONFIGS
+    with pytest.raises(SystemExit):
+        bench.parse_args(["-m", "ZPC"])                                            # the comparator is another algorithm: refused, loudly
+    with pytest.raises(SystemExit):
+        bench.parse_args(["--backend", "gloo"])                                    # gloo only as the CPU rehearsal (--dry-run)
