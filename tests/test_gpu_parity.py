@@ -1224,3 +1224,72 @@ def test_random_points_against_the_oracle_only_chain(built, case, npts):
         np.testing.assert_allclose(out["xbar"][b, 1], sol["xbar"][1], atol=REL * (1 + np.abs(sol["xbar"]).max()))
         checked += 1
     assert checked >= npts // 2, checked
+
+
+@pytest.mark.parametrize("n,m,N,k0,seed", [(3, 2, 6, None, 1), (6, 3, 5, None, 2), (8, 4, 4, None, 3), (3, 2, 8, 2, 4), (1, 1, 6, None, 5), (7, 1, 5, 1, 6)])
+def test_random_systems_at_odd_sizes_against_the_oracle_only_chain(built, n, m, N, k0, seed):
+    """Systems nobody tuned for: random stable (A, B) with n = 1 ... 8 states and m = 1 ... 4 inputs (the limits of the kernels), random
+    zonotopes, quadratic + L1 loss, full and simplified problems.  Data, identification, formulation and solution by the ORACLE alone
+    (oracle.harness / oracle.collapsed / oracle.qp_ipm with KKT certificate); the device gets the same data set and gain through the
+    product's front end.  Objective, consumed input and state; then a short closed loop against the C oracle."""
+    from oracle import collapsed as OC, harness as H
+    from oracle.qp_ipm import solve_qp
+    from oracle.zonolite import Zonotope as OZ
+    from tzddpc_amd import TZDDPC, Data, SystemZonotopes, Theta, Zonotope
+    from tzddpc_amd.dist import vertex_noise
+    rng = np.random.default_rng(1000 + seed)
+    A = rng.standard_normal((n, n)); A *= 0.9 / np.abs(np.linalg.eigvals(A)).max()
+    B = rng.standard_normal((n, m))
+    xc = 0.5 * rng.standard_normal(n)
+    s = dict(A=A, B=B, X0=OZ(xc, np.zeros((n, 1))), U=OZ(np.zeros(m), 2.0 * np.eye(m)),
+             W=OZ(np.zeros(n), 0.002 * (np.eye(n) + 0.3 * rng.standard_normal((n, n)))), X=OZ(np.zeros(n), 6.0 * np.eye(n)), T=60 + 12 * (n + m))
+    u, x = H.generate_trajectories(A, B, s["X0"], s["U"], s["W"], 1, s["T"], rng)
+    idn = H.identify(u, x, s["W"])
+
+    def oloss(nxi, x_idx, u_idx):
+        from oracle.literal import AffineLoss
+        L = AffineLoss()
+        Hn = x_idx.shape[0] - 1 if u_idx is None else u_idx.shape[0]
+        for i in range(Hn):
+            F = np.zeros((n, nxi)); F[np.arange(n), x_idx[i]] = 1.0
+            L.sq.append((1.0, F, np.zeros(n)))
+            if u_idx is not None:
+                for j in u_idx[i]:
+                    f = np.zeros(nxi); f[j] = 1.0
+                    L.ab.append((5e-2, f, 0.0))
+        return L
+
+    def ploss(uu, xx):
+        from tzddpc_amd import cplite as cp
+        cost = 0
+        for i in range(uu.shape[0]):
+            cost += cp.norm(xx[i, :], p=2) ** 2 + 5e-2 * cp.norm(uu[i], p=1)
+        return cost
+    zon = SystemZonotopes(*(Zonotope(np.asarray(s[k].center), np.asarray(s[k].generators)) for k in ("X0", "U", "X", "W")))
+    ctl = TZDDPC(Data(u, x))
+    ctl.build_zonotopes_theta(zon, theta=Theta(idn["K"], np.zeros_like(A), np.zeros_like(B)))
+    if k0 is None:
+        ctl.build_problem(N, ploss, common.nocons)
+    else:
+        ctl.build_problem_simplified(k0, N, ploss, common.nocons)
+    Bn = 6
+    x0 = xc[None] + 0.1 * rng.standard_normal((Bn, n)); e0 = 0.01 * rng.standard_normal((Bn, n)); e0[0] = 0.0
+    out = ctl.solve_batch(x0, e0)
+    assert (out["status"] == 0).all(), out["status"]
+    for b in range(Bn):
+        cq = OC.build_collapsed(idn["A"], idn["B"], idn["MdataK"], idn["Mdelta"], idn["K"], s["W"], s["X"], s["U"], N, e0[b], x0[b], oloss, None, k0)
+        r = solve_qp(cq["P"], cq["q"], cq["A"], cq["l"], cq["u"], tol=1e-12)
+        assert r.status == "solved" and max(r.cert["primal"], r.cert["dual"], r.cert["comp"]) < 1e-9
+        v, xb = OC.extract(cq, r.x)
+        cost = r.obj + cq["r"]
+        assert abs(out["cost"][b] - cost) <= 1e-7 * (1 + abs(cost)), (out["cost"][b], cost)
+        np.testing.assert_allclose(out["v"][b, 0], np.asarray(v).reshape(N, m)[0], atol=REL * (1 + np.abs(v).max()))
+        np.testing.assert_allclose(out["xbar"][b, 1], np.asarray(xb).reshape(N + 1, n)[1], atol=REL * (1 + np.abs(xb).max()))
+    Wv = zon.W.compute_vertices()
+    noise = Wv[np.random.default_rng(7).integers(0, Wv.shape[0], size=(32, 12))]
+    xs = np.tile(xc, (32, 1))
+    dev = ctl.simulate_batch(xs, noise, A, B)
+    ref = common.c_oracle_for(ctl).simulate_batch(xs, noise, A, B, threads=16)
+    assert (dev["status"] == 0).all() and (ref["status"] == 0).all()
+    np.testing.assert_allclose(dev["x"], ref["x"], rtol=0, atol=REL * (1 + np.abs(ref["x"]).max()))
+    np.testing.assert_allclose(dev["u"], ref["u"], rtol=0, atol=REL * (1 + np.abs(ref["u"]).max()))
