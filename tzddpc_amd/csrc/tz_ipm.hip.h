@@ -10,6 +10,14 @@
 // row-vector staging buffer, so that four workgroups fit on a CU for the benchmark sizes.
 #pragma once
 
+// TZ_DUP = k (diagnostic builds only, tools/dup_phases.sh): phase k of the fused step is executed TZ_DUP_N more times -- same results, and the
+// slowdown is the cost of that phase in the production schedule (no clocks in the instruction stream)
+#ifndef TZ_DUP
+#define TZ_DUP 0
+#endif
+#ifndef TZ_DUP_N
+#define TZ_DUP_N 1
+#endif
 #ifndef TZ_MINWAVES
 #define TZ_MINWAVES 4
 #endif
@@ -278,6 +286,24 @@ __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double*
     for (; e < L; ++e) a0 += val[(size_t)e * TZ_THREADS] * in[idx[(size_t)e * TZ_THREADS]];
     pl[v0 + t] = a0 + a1;
   }
+#if TZ_DUP == 20
+  for (int dup = 0; dup < TZ_DUP_N; ++dup) {
+    asm volatile("" ::: "memory");
+    for (int v0 = 0; v0 < p.eg.VL; v0 += TZ_THREADS) {
+      const double* val = p.eg.val + (size_t)v0 * L + t;
+      const unsigned short* idx = p.eg.idx + (size_t)v0 * L + t;
+      double a0 = 0.0, a1 = 0.0;
+      int e = 0;
+      for (; e + 3 < L; e += 4) {
+        const double x0 = val[(size_t)e * TZ_THREADS], x1 = val[(size_t)(e + 1) * TZ_THREADS], x2 = val[(size_t)(e + 2) * TZ_THREADS], x3 = val[(size_t)(e + 3) * TZ_THREADS];
+        const int i0 = idx[(size_t)e * TZ_THREADS], i1 = idx[(size_t)(e + 1) * TZ_THREADS], i2 = idx[(size_t)(e + 2) * TZ_THREADS], i3 = idx[(size_t)(e + 3) * TZ_THREADS];
+        a0 += x0 * in[i0]; a1 += x1 * in[i1]; a0 += x2 * in[i2]; a1 += x3 * in[i3];
+      }
+      for (; e < L; ++e) a0 += val[(size_t)e * TZ_THREADS] * in[idx[(size_t)e * TZ_THREADS]];
+      pl[v0 + t] = a0 + a1;
+    }
+  }
+#endif
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < MAXR; ++k) {
@@ -288,6 +314,20 @@ __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double*
     for (int j = 0; j < cnt; ++j) a += pl[first + j];
     out[k] = a;
   }
+#if TZ_DUP == 21
+  for (int dup = 0; dup < TZ_DUP_N; ++dup) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      double a = 0.0;
+      int sg = rseg[k];
+      asm volatile("" : "+v"(sg));
+      const int first = sg & 0xffff, cnt = sg >> 16;
+      for (int j = 0; j < cnt; ++j) a += pl[first + j];
+      out[k] = a;
+    }
+  }
+#endif
 }
 
 // Partial sums of G'in by the 192 threads of waves 1-3 (the caller keeps wave 0 out); `in` (mi entries), pl (et.VL doubles) in
@@ -427,7 +467,8 @@ __device__ inline double tz_row_ror(double v) {                          // valu
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-template <int R0, int R1>
+// DRY (diagnostic builds, TZ_DUP = 11 / 12): 1 = the operand loop alone, 2 = the fold alone; results kept alive, nothing stored
+template <int R0, int R1, int DRY = 0>
 __device__ inline void tz_gram_rows(const IpmParams& p, double* Hq, const double* Pq, const double* wv, const int* sm, const int h, unsigned long long* pacc) {
   unsigned long long tq0 = pacc ? __builtin_amdgcn_s_memtime() : 0;
   const int lane = tz_tid() & 63;
@@ -469,10 +510,19 @@ __device__ inline void tz_gram_rows(const IpmParams& p, double* Hq, const double
     }
   };
   TzGStage s0, s1;
+  if (DRY != 2) {
   load(h, s0);
   for (int s = h; s < S; s += 4) {
     load(s + 2, s1); mma(s0);
     load(s + 4, s0); mma(s1);
+  }
+  }
+  if (DRY != 0) {
+#pragma unroll
+    for (int a = 0; a < R1 - R0; ++a)
+#pragma unroll
+      for (int J = 0; J < R1; ++J) asm volatile("" : "+v"(acc[a][J]));
+    if (DRY == 1) return;
   }
   if (pacc) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); pacc[PH_GRAM_LOOP] += t1 - tq0; tq0 = t1; }
   // fold the four patch rows (blk) of every tile with two row rotations (every lane of a row of 16 then holds the tile sum),
@@ -484,6 +534,13 @@ __device__ inline void tz_gram_rows(const IpmParams& p, double* Hq, const double
 #pragma unroll
     for (int J = 0; J < R1; ++J)
       if (J <= a + R0) { double v = acc[a][J]; v += tz_row_ror<4>(v); v += tz_row_ror<8>(v); acc[a][J] = v; }
+  if (DRY == 2) {
+#pragma unroll
+    for (int a = 0; a < R1 - R0; ++a)
+#pragma unroll
+      for (int J = 0; J < R1; ++J) asm volatile("" :: "v"(acc[a][J]));
+    return;
+  }
   for (int hh = 0; hh < 2; ++hh) {
     if (h == hh) {
 #pragma unroll
@@ -506,6 +563,13 @@ __device__ inline void tz_gram_rows(const IpmParams& p, double* Hq, const double
   }
 }
 
+template <int DRY = 0>
+__device__ inline void tz_form_H_ksplit_dry(const IpmParams& p, double* Hq, const double* Pq, const double* wv, const int* sm) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = wave >> 1, h = wave & 1;
+  if (p.Tz > 7) { if (g == 0) tz_gram_rows<0, 7, DRY>(p, Hq, Pq, wv, sm, h, nullptr); else tz_gram_rows<7, 10, DRY>(p, Hq, Pq, wv, sm, h, nullptr); }
+  else          { if (g == 0) tz_gram_rows<0, 5, DRY>(p, Hq, Pq, wv, sm, h, nullptr); else tz_gram_rows<5, 7, DRY>(p, Hq, Pq, wv, sm, h, nullptr); }
+}
 __device__ inline void tz_form_H_ksplit(const IpmParams& p, double* Hq, const double* Pq, const double* wv, const int* sm, unsigned long long* pacc) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = wave >> 1, h = wave & 1;
@@ -1070,6 +1134,9 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
       const int* pwl = (const int*)(Tt + (F.tube.pmax > 0 ? F.tube.pmax : 1) * (n + m) * n + 3 * n * n + 2 * n * m + n + n * nv + nv);
       if (n == 2 && m == 1) tz_tube_block<2, 1>(F.tube, tbl, Tt, pwl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS);
       else tz_tube_block(F.tube, tbl, Tt, pwl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS);
+#if TZ_DUP == 1
+      for (int dup = 0; dup < TZ_DUP_N; ++dup) { __syncthreads(); tz_tube_block<2, 1>(F.tube, tbl, Tt, pwl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS); }
+#endif
     }
     __syncthreads();
     TZ_STAMP(PH_TUBE);
@@ -1082,6 +1149,14 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     }
     if (bad) flag[1] = 1;
     TZ_ROWS(k, r) TZ_SET_H(k, r, csr_row(F.hmap, r, thl));
+#if TZ_DUP == 2
+    for (int dup = 0; dup < TZ_DUP_N; ++dup) {
+      asm volatile("" ::: "memory");
+      for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? csr_row(F.qmap, c, thl) : 0.0; }
+      for (int r = t; r < F.npar; r += TZ_THREADS) { const double v = csr_row(F.parmap, r, thl); if (!(v >= F.par_lo[r] - 1e-9) || !(v <= F.par_hi[r] + 1e-9)) flag[1] = 1; }
+      TZ_ROWS(k, r) TZ_SET_H(k, r, csr_row(F.hmap, r, thl));
+    }
+#endif
   } else {
     for (int c = t; c < nzp; c += TZ_THREADS) qv[c] = (c < nz) ? pk.q[(size_t)b * nz + c] : 0.0;
     TZ_ROWS(k, r) TZ_SET_H(k, r, pk.h[(size_t)b * mi + r]);
@@ -1106,6 +1181,16 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part);     // P x by wave 0 (stays in `part` for the objective)
     else tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);                                   // G'lambda by waves 1-3
     __syncthreads();
+#if TZ_DUP == 5
+    for (int dup = 0; dup < TZ_DUP_N; ++dup) {
+      asm volatile("" ::: "memory");
+      if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part); else tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
+      __syncthreads();
+    }
+#endif
+#if TZ_DUP == 6
+    for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); __syncthreads(); }
+#endif
     TZ_STAMP(PH_RD_B);
     double e1 = 0.0;
     if (nzp <= 64) {
@@ -1167,11 +1252,17 @@ retry_solve:
     // G x of the starting point: inside a launch gx_ still holds it (it followed x through the iterations of the previous
     // step); it is formed afresh every eighth step so that rounding does not accumulate along a trajectory
     if (src != 2 || (step & 7) == 0 || retried || shifted) { tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
+#if TZ_DUP == 3
+    for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
+#endif
     TZ_STAMP(PH_WARM_A);
     double viol = 0.0;
     TZ_ROWS(k, r) { const double hv = TZ_H(k, r); viol = fmax(viol, TZ_GX(k, r) - hv); sch = fmax(sch, fabs(hv)); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
     tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red, rpar);      // also the scales of the stopping test
+#if TZ_DUP == 4
+    for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" : "+v"(viol), "+v"(scq), "+v"(sch)); tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red, rpar); }
+#endif
     TZ_STAMP(PH_WARM_B);
     const double sig = fmin(fmax(pk.warm_floor, pk.warm_gain * viol), pk.warm_cap);
     const double sig2 = sig * sig;
@@ -1276,6 +1367,12 @@ retry_solve:
 #endif
     if constexpr (TT) tz_gram_tt<TZ_TT_GU(MINW), TZ_TT_NST>(p, Hq, vin, (PROF && t == 0) ? acc_ph : nullptr); else tz_gram(p, Hq, Pq, vin, kl, (PROF && t == 0) ? acc_ph : nullptr);
     __syncthreads();
+#if TZ_DUP == 11 || TZ_DUP == 12
+    if constexpr (!TT) for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_form_H_ksplit_dry<TZ_DUP - 10>(p, Hq, Pq, vin, kl); }
+#endif
+#if TZ_DUP == 7
+    if constexpr (!TT) for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_gram(p, Hq, Pq, vin, kl, nullptr); __syncthreads(); }
+#endif
     TZ_STAMP(PH_FORM);
     TZ_FRESH_T();
     if (rlev != 0) {
@@ -1356,8 +1453,14 @@ retry_solve:
     if constexpr (TT) TZ_TT_SOLVE(p, Hq, dinv, r1v, tmpz, dxv);
     else if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, have_y ? tmpz : r1v, dxv, have_y); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
+#if TZ_DUP == 9
+    if constexpr (!TT) for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_chol_solve_wave(p, Hq, dinv, have_y ? tmpz : r1v, dxv, have_y); __syncthreads(); }
+#endif
     TZ_STAMP(PH_SOLVE);
     tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, dxv, pl, rseg_, g_);
+#if TZ_DUP == 10
+    for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, dxv, pl, rseg_, g_); }
+#endif
     TZ_STAMP(PH_GEMV);
 #if TZ_PRIO_ELEM
     __builtin_amdgcn_s_setprio(TZ_PRIO_ELEM);
@@ -1416,6 +1519,9 @@ retry_solve:
     if constexpr (TT) TZ_TT_SOLVE(p, Hq, dinv, r1v, tmpz, dxv);
     else if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, dxv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
+#if TZ_DUP == 8
+    if constexpr (!TT) for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_chol_solve_wave(p, Hq, dinv, r1v, dxv); __syncthreads(); }
+#endif
     TZ_STAMP(PH_SOLVE);
     tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, dxv, pl, rseg_, g_);
     TZ_STAMP(PH_GEMV);
@@ -1548,6 +1654,21 @@ retry_solve:
       }
     }
     __syncthreads();
+#if TZ_DUP == 15
+    for (int dup = 0; dup < TZ_DUP_N; ++dup) {
+      asm volatile("" ::: "memory");
+      for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = cDz[c] * xv[F.fin.vpos ? F.fin.vpos[c] : c];
+      __syncthreads();
+      const int ln = t & 63;
+      for (int i = __builtin_amdgcn_readfirstlane(t >> 6); i < n; i += TZ_NWAVES) {
+        double a = (ln < n) ? cPhi[i * n + ln] * x0[ln] : 0.0;
+        for (int c = ln; c < nv; c += 64) a += cGam[i * nv + c] * dxv[c];
+        a = tz_wave_reduce<RED_SUM>(a);
+        if (ln == 0) tmpz[i] = a;
+      }
+      __syncthreads();
+    }
+#endif
     TZ_STAMP(PH_EPI_B);
     if (t < 64) {
       const PlantParams& Q = F.plant;
