@@ -1226,9 +1226,10 @@ def test_random_points_against_the_oracle_only_chain(built, case, npts):
     assert checked >= npts // 2, checked
 
 
-@pytest.mark.parametrize("n,m,N,k0,seed", [(3, 2, 6, None, 1), (6, 3, 5, None, 2), (8, 4, 4, None, 3), (3, 2, 8, 2, 4), (1, 1, 6, None, 5), (7, 1, 5, 1, 6)])
+@pytest.mark.parametrize("n,m,N,k0,seed", [(3, 2, 6, None, 1), (6, 3, 5, None, 2), (8, 4, 4, None, 3), (3, 2, 8, 2, 4), (1, 1, 6, None, 5), (7, 1, 5, 1, 6),
+                                            (12, 5, 4, None, 7), (16, 8, 3, None, 8), (10, 2, 5, 1, 9)])
 def test_random_systems_at_odd_sizes_against_the_oracle_only_chain(built, n, m, N, k0, seed):
-    """Systems nobody tuned for: random stable (A, B) with n = 1 ... 8 states and m = 1 ... 4 inputs (the limits of the kernels), random
+    """Systems nobody tuned for: random stable (A, B) with n = 1 ... 16 states and m = 1 ... 8 inputs (the limits of the MPC path), random
     zonotopes, quadratic + L1 loss, full and simplified problems.  Data, identification, formulation and solution by the ORACLE alone
     (oracle.harness / oracle.collapsed / oracle.qp_ipm with KKT certificate); the device gets the same data set and gain through the
     product's front end.  Objective, consumed input and state; then a short closed loop against the C oracle."""

@@ -47,8 +47,9 @@ template <int NCT, int MCT>
 __global__ __launch_bounds__(256) void tz_genstack_kernel(GenstackParams q) {
   constexpr bool GEN = (NCT == 0);
   constexpr int NC = GEN ? TZ_NMAX : NCT, MC = GEN ? TZ_MMAX : MCT, PCM = NC + MC;
+  constexpr int GTILE = GEN ? 8 : TZ_GS_TILE;       // generators per LDS tile (the any-size instance: 8 x 16 x 25 doubles = 25 KB)
   const int n = GEN ? q.n : NCT, m = GEN ? q.m : MCT, PC = n + m, REC = n * (1 + PC);
-  __shared__ double tile[TZ_GS_TILE * NC * (1 + PCM)];
+  __shared__ double tile[GTILE * NC * (1 + PCM)];
   __shared__ double Ks[MC * NC];
   const GsChunk ch = q.chunks[blockIdx.x];
   const int t = threadIdx.x, b = blockIdx.y * 256 + t;
@@ -69,15 +70,15 @@ __global__ __launch_bounds__(256) void tz_genstack_kernel(GenstackParams q) {
   for (int i = 0; i < NC; ++i) ax[i] = 0.0;
 #pragma unroll
   for (int j = 0; j < MC; ++j) au[j] = 0.0;
-  for (int g0 = ch.g0; g0 < ch.g1; g0 += TZ_GS_TILE) {
-    const int ng = min(TZ_GS_TILE, ch.g1 - g0);
+  for (int g0 = ch.g0; g0 < ch.g1; g0 += GTILE) {
+    const int ng = min(GTILE, ch.g1 - g0);
     __syncthreads();                                             // the previous tile has been consumed
     {
       // contiguous copy of ng records: 16 bytes per lane and pass (records are 8-byte aligned doubles; the stack base is 16-byte
       // aligned and REC * TZ_GS_TILE is even, so every tile starts on a 16-byte boundary when REC is even; odd REC: 8-byte path)
       const double* srcp = q.recs + (size_t)g0 * REC;
       const int nd = ng * REC;
-      if (((REC * TZ_GS_TILE) & 1) == 0 && ((((size_t)g0 * REC) & 1) == 0)) {
+      if (((REC * GTILE) & 1) == 0 && ((((size_t)g0 * REC) & 1) == 0)) {
         const double2* s2 = reinterpret_cast<const double2*>(srcp);
         double2* d2 = reinterpret_cast<double2*>(tile);
         for (int i = t; i < (nd >> 1); i += 256) d2[i] = s2[i];

@@ -16,7 +16,9 @@
 // One wave per data set (the whole problem is (n + m + n) x (T - 1) <= 20 x 399 numbers).
 #pragma once
 
-#define TZ_ID_PMAX 12            // n + m <= 12 (TZ_NMAX + TZ_MMAX)
+#define TZ_ID_NMAX 8              // K0: dim_x <= 8, dim_u <= 4 (tile counts below)
+#define TZ_ID_MMAX 4
+#define TZ_ID_PMAX 12            // n + m <= 12
 #define TZ_ID_RT 5               // tile rows of Y = [D; Xp' - c_W]: ceil((12 + 8) / 4)
 #define TZ_ID_CT 3               // tile columns (rows of D)
 
@@ -36,7 +38,7 @@ struct IdentifyParams {
 
 __global__ __launch_bounds__(64) void tz_identify_kernel(IdentifyParams q) {
   __shared__ double S[TZ_ID_PMAX * TZ_ID_PMAX];          // D D', then its Cholesky factor (lower)
-  __shared__ double R[TZ_NMAX * TZ_ID_PMAX];             // (Xp' - c_W) D'
+  __shared__ double R[TZ_ID_NMAX * TZ_ID_PMAX];             // (Xp' - c_W) D'
   __shared__ double Si[TZ_ID_PMAX * TZ_ID_PMAX];         // (D D')^-1
   __shared__ int bad;
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -147,11 +149,11 @@ __global__ __launch_bounds__(64) void tz_identify_kernel(IdentifyParams q) {
     }
   }
   // ---- s = sum_t |P[t, :]|, sK = sum_t |P[t, :] [I; K]|  with P[t, :] = (D D')^-1 D[:, t]; lanes over t ------------------------
-  double ss[TZ_ID_PMAX], sk[TZ_NMAX];
+  double ss[TZ_ID_PMAX], sk[TZ_ID_NMAX];
 #pragma unroll
   for (int c = 0; c < TZ_ID_PMAX; ++c) ss[c] = 0.0;
 #pragma unroll
-  for (int c = 0; c < TZ_NMAX; ++c) sk[c] = 0.0;
+  for (int c = 0; c < TZ_ID_NMAX; ++c) sk[c] = 0.0;
   for (int t = lane; t < T1; t += 64) {
     double d[TZ_ID_PMAX], pr[TZ_ID_PMAX];
 #pragma unroll
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64) void tz_identify_kernel(IdentifyParams q) {
     }
     if (Kb) {
 #pragma unroll
-      for (int c = 0; c < TZ_NMAX; ++c) {
+      for (int c = 0; c < TZ_ID_NMAX; ++c) {
         if (c < n) {
           double a = pr[c];
 #pragma unroll
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(64) void tz_identify_kernel(IdentifyParams q) {
   for (int c = 0; c < TZ_ID_PMAX; ++c) { const double v = tz_wave_reduce<RED_SUM>(ss[c]); if (lane == 0 && c < p) q.s[(size_t)b * p + c] = v; }
   if (Kb && q.sK) {
 #pragma unroll
-    for (int c = 0; c < TZ_NMAX; ++c) { const double v = tz_wave_reduce<RED_SUM>(sk[c]); if (lane == 0 && c < n) q.sK[(size_t)b * n + c] = v; }
+    for (int c = 0; c < TZ_ID_NMAX; ++c) { const double v = tz_wave_reduce<RED_SUM>(sk[c]); if (lane == 0 && c < n) q.sK[(size_t)b * n + c] = v; }
   }
   if (lane == 0) q.status[b] = bad ? 2 : 0;
 }

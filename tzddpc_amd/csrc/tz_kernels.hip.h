@@ -20,8 +20,8 @@
 #endif
 #define TZ_THREADS 256
 #define TZ_NWAVES 4
-#define TZ_NMAX 8          // max dim_x supported by the tube kernel's register arrays
-#define TZ_MMAX 4
+#define TZ_NMAX 16         // max dim_x / dim_u of the MPC path (register arrays of the plant update, LDS slots of the closed-loop state);
+#define TZ_MMAX 8          // K0 (tz_identify.hip.h) and the gain kernels (tz_gain.hip.h) keep their own limits of 8 / 4
 
 // Affine map rows over theta in ELL form: entry e of row r at [e * rows + r] (coalesced over rows), W entries per row, rows
 // with fewer non-zeros padded with (0.0, column 0).  No row pointers: every load of a row is independent of the others.

@@ -382,7 +382,7 @@ int tz_identify_batch(int device, int32_t B, int32_t T, int32_t n, int32_t m, co
                       double* C, double* s, double* sK, double* CK, int32_t* status, int mem) {
   if (!u || !x || !w_center || !C || !s || !status) TZ_FAIL(TZ_ERR_INVALID, "null argument");
   if (B <= 0 || T < 2) TZ_FAIL(TZ_ERR_INVALID, "B must be positive and T at least 2");
-  if (n < 1 || n > TZ_NMAX || m < 1 || m > TZ_MMAX) TZ_FAIL(TZ_ERR_UNSUPPORTED, "dim_x must be 1..%d and dim_u 1..%d", TZ_NMAX, TZ_MMAX);
+  if (n < 1 || n > TZ_ID_NMAX || m < 1 || m > TZ_ID_MMAX) TZ_FAIL(TZ_ERR_UNSUPPORTED, "identification on the device (K0): dim_x must be 1..%d and dim_u 1..%d", TZ_ID_NMAX, TZ_ID_MMAX);
   if (K && (!sK || !CK)) TZ_FAIL(TZ_ERR_INVALID, "sK and CK are required when K is given");
   if (mem != TZ_MEM_HOST && mem != TZ_MEM_DEVICE) TZ_FAIL(TZ_ERR_INVALID, "mem must be TZ_MEM_HOST or TZ_MEM_DEVICE");
   int ndev = 0;
@@ -1032,6 +1032,8 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
     p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg, wgs_per_cu, ttk);
   }
   if (!p->ipm_fn) TZ_FAIL(TZ_ERR_UNSUPPORTED, "this development build (TZ_ONLY_SMALL) carries only the mi <= 256, nz <= 64 kernel");
+  // the tube pass of the fused step keeps |C_K^l e0| (pmax n doubles) in the factor storage, which is free at that point
+  if ((size_t)std::max(d->pmax, 1) * d->n > p->hsize) TZ_FAIL(TZ_ERR_UNSUPPORTED, "pmax * dim_x = %d exceeds the factor storage (%zu doubles) the tube pass borrows", std::max(d->pmax, 1) * d->n, p->hsize);
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
   if (const char* e = getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
   if (p->prof && !TZ_PROFILE) TZ_FAIL(TZ_ERR_INVALID, "TZ_PROF=1 needs the diagnostic build of the library (libtzddpc_hip_prof.so)");
