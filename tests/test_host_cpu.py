@@ -308,3 +308,25 @@ def test_bench_accepts_the_reference_harness_flags():
         bench.parse_args(["-m", "ZPC"])                                            # the comparator is another algorithm: refused, loudly
     with pytest.raises(SystemExit):
         bench.parse_args(["--backend", "gloo"])                                    # gloo only as the CPU rehearsal (--dry-run)
+
+
+def test_zonotope_polygon_matches_the_vertex_enumeration():
+    """``Z.reduce(order).polygon`` of the reference's plots (examples/1.double_integrator_sim.py:170,174): boundary of a 2-D zonotope,
+    counter-clockwise, equal as a set to the hull of the 2^g enumerated points."""
+    from scipy.spatial import ConvexHull
+    from tzddpc_amd.zonotope import Zonotope
+    rng = np.random.default_rng(3)
+    for g in (1, 2, 3, 6, 9):
+        Z = Zonotope(rng.standard_normal(2), rng.standard_normal((2, g)))
+        V = Z.polygon_vertices()
+        assert V.shape == (2 * g, 2)
+        W = Z.compute_vertices()
+        hull = W[ConvexHull(W).vertices] if g > 1 else W
+        a = np.array(sorted(map(tuple, np.round(V, 10)))); b = np.array(sorted(map(tuple, np.round(hull, 10))))
+        np.testing.assert_allclose(a, b, atol=1e-9)
+        if g > 1:
+            assert 0.5 * np.sum(V[:, 0] * np.roll(V[:, 1], -1) - np.roll(V[:, 0], -1) * V[:, 1]) > 0
+    boxed = Zonotope([0.0, 0.0], np.array([[1.0, 0.0, 0.5], [0.0, 2.0, 0.5]])).reduce(1)
+    assert boxed.polygon_vertices().shape == (4, 2)
+    with pytest.raises(ValueError):
+        Zonotope(np.zeros(3), np.eye(3)).polygon_vertices()

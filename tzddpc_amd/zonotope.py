@@ -87,6 +87,31 @@ class Zonotope:
     def reduce(self, order: int) -> "Zonotope":
         return Zonotope(self.center, girard_box(self.generators, order))
 
+    def polygon_vertices(self) -> np.ndarray:
+        """Boundary of a 2-dimensional zonotope, counter-clockwise, (2 g', 2) with g' the non-zero generators: the generators turned into
+        the upper half-plane and sorted by angle are the edges of one half of the boundary (any number of generators, no 2^g enumeration)."""
+        if self.dimension != 2:
+            raise ValueError("polygon: the zonotope must be 2-dimensional")
+        G = self.generators[:, np.any(self.generators != 0.0, axis=0)]
+        if G.shape[1] == 0:
+            return self.center[None, :].copy()
+        G = np.where((G[1] < 0) | ((G[1] == 0) & (G[0] < 0)), -G, G)
+        G = G[:, np.argsort(np.arctan2(G[1], G[0]), kind="stable")]
+        start = self.center - G.sum(axis=1)                      # the lowest vertex
+        half = start[None, :] + 2.0 * np.cumsum(G, axis=1).T     # ... up the right side to the highest
+        return np.concatenate([start[None, :], half[:-1], 2.0 * self.center[None, :] - start[None, :], 2.0 * self.center[None, :] - half[:-1]], axis=0)
+
+    @property
+    def polygon(self):
+        """What the reference's plotting code draws (``examples/1.double_integrator_sim.py:170,174``: ``Z.reduce(3).polygon`` in a
+        PatchCollection): a ``matplotlib.patches.Polygon`` when matplotlib is installed, the vertex array otherwise."""
+        V = self.polygon_vertices()
+        try:
+            from matplotlib.patches import Polygon
+        except ImportError:
+            return V
+        return Polygon(V, closed=True)
+
     def __repr__(self):
         return f"Zonotope(dim={self.dimension}, generators={self.num_generators})"
 
