@@ -141,23 +141,32 @@ struct GsChunkM { int seg, src, q0, nq; };       // groups [q0, q0 + nq) of 4 ge
 
 struct GenstackMParams {
   int B, n, m, N, nchunk, ntt, nsub;             // ntt = blocks per chunk: trajectory tiles of 256, or (SPLIT) nsub sub-ranges of its tiles
-  const double* recs;                            // groups of GD = 4 P (P + 1) doubles
+  const double* recs;                            // groups of GD = 4 R (P + 1) doubles (R = P: K rows appended by the host; R = n: formed in the kernel)
+  const double* K;                               // m x n (used when R < P)
   const GsChunkM* chunks;
   const double* e0;                              // B x n
   const double* zeta;                            // B x N x (n+m)
   double* partial;                               // nchunk x B x (n+m)
 };
 
-template <int P> struct GsTile {
-  static constexpr int GD = 4 * P * (P + 1);                                      // doubles per group of 4 generators
+template <int R, int P> struct GsTile {
+  static constexpr int GD = 4 * R * (P + 1);                                      // doubles per group of 4 generators
   static constexpr int GT = (TZ_GS_TILE_DOUBLES / GD >= 64) ? 64 : (TZ_GS_TILE_DOUBLES / GD >= 32) ? 32 : (TZ_GS_TILE_DOUBLES / GD >= 16) ? 16 : (TZ_GS_TILE_DOUBLES / GD >= 8) ? 8 : 4;   // groups per tile
   static constexpr int ND2 = GT * GD / 2;                                         // double2 per tile
   static constexpr int LD = (ND2 + 255) / 256;                                    // double2 per thread and tile
 };
 
-template <int P, int NQ, bool SPLIT>
+// R stored rows per generator, inner dimension P = n + m.  R = P: the m rows K M, K m0 come appended from the host.  R = n (one input:
+// the reference's systems): the stack holds only [m0 | M] -- 1 / (n + 1) fewer bytes and matrix instructions -- and rad^u = sum |K g| is formed
+// from the n results of a generator group, which sit in the same lanes (one fused multiply-add per component and trajectory group).
+template <int R, int P, int NQ, bool SPLIT>
 __global__ __launch_bounds__(256) void tz_genstack_mfma_kernel(GenstackMParams q) {
-  constexpr int KS = (P + 3) / 4, GD = GsTile<P>::GD, GT = GsTile<P>::GT, LD = GsTile<P>::LD;
+  constexpr int KS = (P + 3) / 4, GD = GsTile<R, P>::GD, GT = GsTile<R, P>::GT, LD = GsTile<R, P>::LD, MK = P - R;
+  double kr[MK > 0 ? MK : 1][R];                 // K (uniform: scalar registers)
+#pragma unroll
+  for (int jj = 0; jj < MK; ++jj)
+#pragma unroll
+    for (int c = 0; c < R; ++c) kr[jj][c] = q.K[jj * R + c];
   __shared__ double2 tile2[2][GT * GD / 2 + 2];                   // +2: the last A read of a tile may run 3 doubles past the group
   __shared__ double xred[SPLIT ? 3 * P * NQ * 16 : 1];
   // (chunk, trajectory tile) of this block: the ntt tiles of a chunk are 8 blocks apart -> same XCD, consecutive waves of blocks
@@ -207,14 +216,19 @@ __global__ __launch_bounds__(256) void tz_genstack_mfma_kernel(GenstackMParams q
     for (int i = 0; i < LD; ++i) { const int e = t + 256 * i; if (e < GT * GD / 2) tile2[buf][e] = stage[i]; }
   };
   const int ai = (lane & 3) * P + (lane >> 4);                   // A: generator i = lane & 3, inner entry k = lane >> 4 (+ 4 s)
-  const int ci = 4 * P * P + (lane >> 4);                        // C (D layout): generator i = lane >> 4
+  const int ci = 4 * R * P + (lane >> 4);                        // C (D layout): generator i = lane >> 4
   auto products = [&](int tl) {
     const double* buf = reinterpret_cast<const double*>(tile2[tl & 1]);
     const int ng = min(GT, ch.nq - (t_lo + tl) * GT);
     for (int g = SPLIT ? wave : 0; g < ng; g += SPLIT ? 4 : 1) {
       const double* gb = buf + g * GD;
+      double ku[MK > 0 ? MK : 1][NQ];
 #pragma unroll
-      for (int c = 0; c < P; ++c) {
+      for (int jj = 0; jj < MK; ++jj)
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) ku[jj][qq] = 0.0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) {
         const double m0v = gb[ci + 4 * c];
         double d[NQ];
 #pragma unroll
@@ -226,8 +240,16 @@ __global__ __launch_bounds__(256) void tz_genstack_mfma_kernel(GenstackMParams q
           for (int qq = 0; qq < NQ; ++qq) d[qq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bx[s][qq], d[qq], 0, 0, 0);
         }
 #pragma unroll
-        for (int qq = 0; qq < NQ; ++qq) acc[c][qq] += fabs(d[qq]);
+        for (int qq = 0; qq < NQ; ++qq) {
+          acc[c][qq] += fabs(d[qq]);
+#pragma unroll
+          for (int jj = 0; jj < MK; ++jj) ku[jj][qq] = __builtin_fma(kr[jj][c], d[qq], ku[jj][qq]);
+        }
       }
+#pragma unroll
+      for (int jj = 0; jj < MK; ++jj)
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) acc[R + jj][qq] += fabs(ku[jj][qq]);
     }
   };
   if (t < 2) { tile2[0][GT * GD / 2 + t] = make_double2(0.0, 0.0); tile2[1][GT * GD / 2 + t] = make_double2(0.0, 0.0); }
@@ -296,9 +318,14 @@ __global__ __launch_bounds__(256) void tz_genstack_mfma_kernel(GenstackMParams q
 // workgroup barrier inside the stream, so one wave's loads, another's LDS writes and a third's matrix instructions overlap instead
 // of meeting at a barrier per tile (the SPLIT form of tz_genstack_mfma_kernel: MFMA pipe 44 % busy, HBM at half its achievable rate,
 // neither saturated).  Same arithmetic per wave as there; the four waves' sums meet in LDS in wave order at the end.
-template <int P, int NQ>
+template <int R, int P, int NQ>
 __global__ __launch_bounds__(256) void tz_genstack_mfma_narrow_kernel(GenstackMParams q) {
-  constexpr int KS = (P + 3) / 4, GD = GsTile<P>::GD, GW = (GsTile<P>::GT >= TZ_GS_GWDIV) ? GsTile<P>::GT / TZ_GS_GWDIV : 1;
+  constexpr int KS = (P + 3) / 4, GD = GsTile<R, P>::GD, GW = (GsTile<R, P>::GT >= TZ_GS_GWDIV) ? GsTile<R, P>::GT / TZ_GS_GWDIV : 1, MK = P - R;
+  double kr[MK > 0 ? MK : 1][R];
+#pragma unroll
+  for (int jj = 0; jj < MK; ++jj)
+#pragma unroll
+    for (int c = 0; c < R; ++c) kr[jj][c] = q.K[jj * R + c];
   constexpr int WD2 = GW * GD / 2, LDW = (WD2 + 63) / 64;
   __shared__ double2 wtile[4][2][WD2 + 2];
   __shared__ double xred[3 * P * NQ * 16];
@@ -347,14 +374,19 @@ __global__ __launch_bounds__(256) void tz_genstack_mfma_narrow_kernel(GenstackMP
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  const int ai = (lane & 3) * P + (lane >> 4), ci = 4 * P * P + (lane >> 4);
+  const int ai = (lane & 3) * P + (lane >> 4), ci = 4 * R * P + (lane >> 4);
   auto products = [&](int j) {
     const double* buf = reinterpret_cast<const double*>(wtile[wave][j & 1]);
     const int ng = min(GW, ch.nq - (t_lo + wave + 4 * j) * GW);
     for (int g = 0; g < ng; ++g) {
       const double* gb = buf + g * GD;
+      double ku[MK > 0 ? MK : 1][NQ];
 #pragma unroll
-      for (int c = 0; c < P; ++c) {
+      for (int jj = 0; jj < MK; ++jj)
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) ku[jj][qq] = 0.0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) {
         const double m0v = gb[ci + 4 * c];
         double d[NQ];
 #pragma unroll
@@ -366,8 +398,16 @@ __global__ __launch_bounds__(256) void tz_genstack_mfma_narrow_kernel(GenstackMP
           for (int qq = 0; qq < NQ; ++qq) d[qq] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bx[s][qq], d[qq], 0, 0, 0);
         }
 #pragma unroll
-        for (int qq = 0; qq < NQ; ++qq) acc[c][qq] += fabs(d[qq]);
+        for (int qq = 0; qq < NQ; ++qq) {
+          acc[c][qq] += fabs(d[qq]);
+#pragma unroll
+          for (int jj = 0; jj < MK; ++jj) ku[jj][qq] = __builtin_fma(kr[jj][c], d[qq], ku[jj][qq]);
+        }
       }
+#pragma unroll
+      for (int jj = 0; jj < MK; ++jj)
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) acc[R + jj][qq] += fabs(ku[jj][qq]);
     }
   };
   if (lane < 2) { wtile[wave][0][WD2 + lane] = make_double2(0.0, 0.0); wtile[wave][1][WD2 + lane] = make_double2(0.0, 0.0); }

@@ -454,11 +454,12 @@ struct tz_genstack {
   int device = 0, n = 0, m = 0, N = 0, nseg = 0, rec = 0, nchunk = 0;
   int64_t G = 0;
   std::vector<int> seg_ptr;                 // literal order
-  DevBuf<double> recs_sorted, recs_lit, recs_mf, c0, cE, cZ, K, partial, in_e0, in_zeta, o_c, o_rx, o_ru, o_Z;
+  DevBuf<double> recs_sorted, recs_lit, recs_mf, recs_mfn, c0, cE, cZ, K, partial, in_e0, in_zeta, o_c, o_rx, o_ru, o_Z;
   DevBuf<int> src_lit, seg_chunk_ptr;
   DevBuf<GsChunk> chunks;
   DevBuf<GsChunkM> chunks_m;                // matrix-core layout (tz_genstack_mfma_kernel): groups of 4 generators, K rows appended
   bool mfma = false;
+  int rows_mf = 0;                          // rows per generator in recs_mf: n + m (K rows appended) or n (formed in the kernel)
   size_t pcap = 0;                          // doubles allocated for `partial`
   bool have_cZ = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -506,37 +507,50 @@ int tz_genstack_create(int device, const tz_genstack_desc* d, tz_genstack** out)
   // matrix-core layout of the sorted stack (dimensions with a compiled instance): per group of 4 generators (a chunk is padded
   // with zero generators) [component c < P][generator i < 4][inner k < P] of Mext = [M; K M], then [c][i] of m0ext = [m0; K m0]
   g->mfma = (p >= 3 && p <= 7) && !getenv("TZ_GS_VALU");
+  // one input (the reference's systems): a second copy of the stack holds only the n rows [m0 | M] -- 1 / (n + 1) fewer bytes and matrix
+  // instructions -- and K g is formed in the kernel; it serves every batch except 33 .. 64 trajectories, where the extra vector
+  // arithmetic of the narrow kernel costs more than the rows save (measured: tools/k1g_ab.sh).  TZ_GS_KROWS=1: appended rows only.
+  g->rows_mf = (m == 1 && !getenv("TZ_GS_KROWS")) ? n : p;
   if (g->mfma && !chunks.empty()) {
-    const int GD = 4 * p * (p + 1);
-    std::vector<GsChunkM> cm; std::vector<double> mf;
+    std::vector<GsChunkM> cm;
     std::vector<double> ext((size_t)p * (p + 1));
-    for (const GsChunk& ch : chunks) {
-      const int ng = ch.g1 - ch.g0, nq = (ng + 3) / 4;
-      const size_t q0 = mf.size() / GD;
-      mf.resize(mf.size() + (size_t)nq * GD, 0.0);
-      for (int gi = 0; gi < ng; ++gi) {
-        const double* r = &srt[(size_t)(ch.g0 + gi) * rec];            // [m0 (n) | M (n x p)]
-        for (int c = 0; c < p; ++c) {
-          double m0e = 0.0;
-          if (c < n) m0e = r[c]; else for (int i = 0; i < n; ++i) m0e += d->K[(size_t)(c - n) * n + i] * r[i];
-          ext[(size_t)c * (p + 1)] = m0e;
-          for (int k = 0; k < p; ++k) {
-            double v = 0.0;
-            if (c < n) v = r[n + c * p + k]; else for (int i = 0; i < n; ++i) v += d->K[(size_t)(c - n) * n + i] * r[n + i * p + k];
-            ext[(size_t)c * (p + 1) + 1 + k] = v;
+    auto layout = [&](int RW, std::vector<double>& mf, bool want_chunks) {
+      const int GD = 4 * RW * (p + 1);
+      for (const GsChunk& ch : chunks) {
+        const int ng = ch.g1 - ch.g0, nq = (ng + 3) / 4;
+        const size_t q0 = mf.size() / GD;
+        mf.resize(mf.size() + (size_t)nq * GD, 0.0);
+        for (int gi = 0; gi < ng; ++gi) {
+          const double* r = &srt[(size_t)(ch.g0 + gi) * rec];            // [m0 (n) | M (n x p)]
+          for (int c = 0; c < RW; ++c) {
+            double m0e = 0.0;
+            if (c < n) m0e = r[c]; else for (int i = 0; i < n; ++i) m0e += d->K[(size_t)(c - n) * n + i] * r[i];
+            ext[(size_t)c * (p + 1)] = m0e;
+            for (int k = 0; k < p; ++k) {
+              double v = 0.0;
+              if (c < n) v = r[n + c * p + k]; else for (int i = 0; i < n; ++i) v += d->K[(size_t)(c - n) * n + i] * r[n + i * p + k];
+              ext[(size_t)c * (p + 1) + 1 + k] = v;
+            }
+          }
+          double* gb = &mf[(q0 + gi / 4) * GD];
+          const int i4 = gi & 3;
+          for (int c = 0; c < RW; ++c) {
+            for (int k = 0; k < p; ++k) gb[c * 4 * p + i4 * p + k] = ext[(size_t)c * (p + 1) + 1 + k];
+            gb[4 * RW * p + 4 * c + i4] = ext[(size_t)c * (p + 1)];
           }
         }
-        double* gb = &mf[(q0 + gi / 4) * GD];
-        const int i4 = gi & 3;
-        for (int c = 0; c < p; ++c) {
-          for (int k = 0; k < p; ++k) gb[c * 4 * p + i4 * p + k] = ext[(size_t)c * (p + 1) + 1 + k];
-          gb[4 * p * p + 4 * c + i4] = ext[(size_t)c * (p + 1)];
-        }
+        if (want_chunks) cm.push_back(GsChunkM{ch.seg, ch.src, (int)q0, nq});       // group offsets are the same in both layouts
       }
-      cm.push_back(GsChunkM{ch.seg, ch.src, (int)q0, nq});
-    }
+    };
+    std::vector<double> mf;
+    layout(p, mf, true);
     for (double v : mf) if (!std::isfinite(v)) TZ_FAIL(TZ_ERR_INVALID, "non-finite generator entry");
     TZ_HIP(g->recs_mf.upload(mf)); TZ_HIP(g->chunks_m.upload(cm));
+    if (g->rows_mf != p) {
+      std::vector<double> mfn;
+      layout(g->rows_mf, mfn, false);
+      TZ_HIP(g->recs_mfn.upload(mfn));
+    }
   }
   TZ_HIP(g->recs_lit.upload(lit)); TZ_HIP(g->recs_sorted.upload(srt));
   TZ_HIP(g->src_lit.upload(d->src, (size_t)std::max<int64_t>(G, 1)));
@@ -601,23 +615,34 @@ static int gs_eval(tz_genstack* g, int B, const double* de0, const double* dz, d
       if (e) nsub = std::min(TZ_GS_MAXSUB, std::max(1, atoi(e)));
     }
     const int ntt = split ? nsub : (B + 255) / 256;
-    GenstackMParams qm{B, n, m, g->N, g->nchunk, ntt, nsub, g->recs_mf.p, g->chunks_m.p, de0, dz, g->partial.p};
+    const bool krows = g->rows_mf == p || (B > 32 && B <= 64);       // which copy of the stack: K rows appended, or formed in the kernel
+    GenstackMParams qm{B, n, m, g->N, g->nchunk, ntt, nsub, krows ? g->recs_mf.p : g->recs_mfn.p, g->K.p, g->chunks_m.p, de0, dz, g->partial.p};
     const dim3 gm((unsigned)(((g->nchunk + 7) / 8) * 8 * ntt));
     const bool narrow = split && !getenv("TZ_GS_NO_NARROW");     // wave-private pipeline (no barrier in the stream); the switch keeps the barrier form
-#define TZ_GS_LAUNCH(PP) do { \
-      if (!split) hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 4, false>), gm, dim3(256), 0, st, qm); \
-      else if (narrow && nq == 1) hipLaunchKernelGGL((tz_genstack_mfma_narrow_kernel<PP, 1>), gm, dim3(256), 0, st, qm); \
-      else if (narrow && nq == 2) hipLaunchKernelGGL((tz_genstack_mfma_narrow_kernel<PP, 2>), gm, dim3(256), 0, st, qm); \
-      else if (narrow) hipLaunchKernelGGL((tz_genstack_mfma_narrow_kernel<PP, 4>), gm, dim3(256), 0, st, qm); \
-      else if (nq == 1) hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 1, true>), gm, dim3(256), 0, st, qm); \
-      else if (nq == 2) hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 2, true>), gm, dim3(256), 0, st, qm); \
-      else hipLaunchKernelGGL((tz_genstack_mfma_kernel<PP, 4, true>), gm, dim3(256), 0, st, qm); } while (0)
-    switch (p) {
-      case 3: TZ_GS_LAUNCH(3); break;
-      case 4: TZ_GS_LAUNCH(4); break;
-      case 5: TZ_GS_LAUNCH(5); break;
-      case 6: TZ_GS_LAUNCH(6); break;
-      default: TZ_GS_LAUNCH(7); break;
+#define TZ_GS_LAUNCH(RR, PP) do { \
+      if (!split) hipLaunchKernelGGL((tz_genstack_mfma_kernel<RR, PP, 4, false>), gm, dim3(256), 0, st, qm); \
+      else if (narrow && nq == 1) hipLaunchKernelGGL((tz_genstack_mfma_narrow_kernel<RR, PP, 1>), gm, dim3(256), 0, st, qm); \
+      else if (narrow && nq == 2) hipLaunchKernelGGL((tz_genstack_mfma_narrow_kernel<RR, PP, 2>), gm, dim3(256), 0, st, qm); \
+      else if (narrow) hipLaunchKernelGGL((tz_genstack_mfma_narrow_kernel<RR, PP, 4>), gm, dim3(256), 0, st, qm); \
+      else if (nq == 1) hipLaunchKernelGGL((tz_genstack_mfma_kernel<RR, PP, 1, true>), gm, dim3(256), 0, st, qm); \
+      else if (nq == 2) hipLaunchKernelGGL((tz_genstack_mfma_kernel<RR, PP, 2, true>), gm, dim3(256), 0, st, qm); \
+      else hipLaunchKernelGGL((tz_genstack_mfma_kernel<RR, PP, 4, true>), gm, dim3(256), 0, st, qm); } while (0)
+    if (krows) {
+      switch (p) {
+        case 3: TZ_GS_LAUNCH(3, 3); break;
+        case 4: TZ_GS_LAUNCH(4, 4); break;
+        case 5: TZ_GS_LAUNCH(5, 5); break;
+        case 6: TZ_GS_LAUNCH(6, 6); break;
+        default: TZ_GS_LAUNCH(7, 7); break;
+      }
+    } else {
+      switch (p) {
+        case 3: TZ_GS_LAUNCH(2, 3); break;
+        case 4: TZ_GS_LAUNCH(3, 4); break;
+        case 5: TZ_GS_LAUNCH(4, 5); break;
+        case 6: TZ_GS_LAUNCH(5, 6); break;
+        default: TZ_GS_LAUNCH(6, 7); break;
+      }
     }
 #undef TZ_GS_LAUNCH
   } else if (g->nchunk > 0) {
