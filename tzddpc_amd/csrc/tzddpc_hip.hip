@@ -651,10 +651,11 @@ static int gs_eval(tz_genstack* g, int B, const double* de0, const double* dz, d
     else if (n == 5 && m == 1) hipLaunchKernelGGL((tz_genstack_kernel<5, 1>), grid, dim3(256), 0, st, q);
     else hipLaunchKernelGGL((tz_genstack_kernel<0, 0>), grid, dim3(256), 0, st, q);
   }
-  TZ_HIP(hipEventRecord(g->ev1, st));
+  TZ_HIP(hipEventRecord(g->ev1, st));          // the stream kernel alone (what rocprofv3 reports for it); the reduction follows
   GsReduceParams r{B, n, m, g->N, g->nseg, nsub, g->seg_chunk_ptr.p, g->partial.p, g->c0.p, g->cE.p, g->have_cZ ? g->cZ.p : nullptr, de0, dz, dc, drx, dru};
   const size_t total = (size_t)B * g->nseg * p;
-  hipLaunchKernelGGL(tz_genstack_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+  if (B <= 64 && n <= 16) hipLaunchKernelGGL(tz_genstack_reduce16_kernel, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0, st, r);   // few trajectories: latency, not bytes
+  else hipLaunchKernelGGL(tz_genstack_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
   TZ_HIP(hipGetLastError());
   return TZ_OK;
 }
