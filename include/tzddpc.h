@@ -214,7 +214,10 @@ int tz_genstack_info(tz_genstack* g, int64_t* generators, int64_t* stack_bytes, 
 
 /* Build-time: upload one problem to `device`.  Stands behind the *result* of
  * TZDDPC.build_problem / build_problem_simplified (reference tzddpc/tzddpc.py:132, :243), i.e. the
- * object `self.problem_full` that solve() later consumes. */
+ * object `self.problem_full` that solve() later consumes.
+ * Sizes: dim_x <= 16, dim_u <= 8, nz <= 256 decision variables, mi <= 1536 one-sided rows, pmax <= 128 (TZ_ERR_UNSUPPORTED beyond;
+ * the reference itself takes any size, tzddpc/tzddpc.py:155-160).  tz_identify_batch: dim_x <= 8, dim_u <= 4; tz_specrad_batch /
+ * tz_adversary_batch: n <= 8. */
 int tz_problem_create(int device, const tz_problem_desc* desc, tz_problem** out);
 int tz_problem_destroy(tz_problem* p);
 

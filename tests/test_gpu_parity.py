@@ -1294,3 +1294,43 @@ def test_random_systems_at_odd_sizes_against_the_oracle_only_chain(built, n, m, 
     assert (dev["status"] == 0).all() and (ref["status"] == 0).all()
     np.testing.assert_allclose(dev["x"], ref["x"], rtol=0, atol=REL * (1 + np.abs(ref["x"]).max()))
     np.testing.assert_allclose(dev["u"], ref["u"], rtol=0, atol=REL * (1 + np.abs(ref["u"]).max()))
+
+
+@pytest.mark.parametrize("n,m,Bn", [(9, 2, 5), (9, 2, 70), (12, 5, 3), (16, 8, 33)])
+def test_literal_tubes_any_size_instance_against_oracle_zonotope_algebra(built, n, m, Bn):
+    """K1g for dimensions without a compiled matrix-core instance (n + m > 7): the any-size kernel (8-generator LDS tile, n <= 16, m <= 8)
+    and both reductions behind it (sixteen lanes per output for <= 64 trajectories, one thread per output above) on a random system,
+    against the oracle's NUMERIC zonotope algebra (oracle.zonolite: Ze[1] = MdataK * <e0, [0]> + (Mdelta * <[xbar0; v0], [0]> + W),
+    reference tzddpc/tzddpc.py:172-176, :205) -- hulls of Ze[0], Ze[1] and the columns of Ze[1] as solve() returns them.  (The symbolic
+    oracle.literal takes minutes at these sizes.)"""
+    from oracle import harness as H
+    from oracle.zonolite import Zonotope as OZ
+    from tzddpc_amd import TZDDPC, Data, SystemZonotopes, Theta, Zonotope
+    rng = np.random.default_rng(500 + n + m)
+    A = rng.standard_normal((n, n)); A *= 0.9 / np.abs(np.linalg.eigvals(A)).max()
+    B = rng.standard_normal((n, m))
+    s = dict(A=A, B=B, X0=OZ(np.zeros(n), np.zeros((n, 1))), U=OZ(np.zeros(m), 2.0 * np.eye(m)),
+             W=OZ(0.01 * rng.standard_normal(n), 0.002 * (np.eye(n) + 0.3 * rng.standard_normal((n, n)))), X=OZ(np.zeros(n), 6.0 * np.eye(n)), T=60 + 12 * (n + m))
+    u, x = H.generate_trajectories(A, B, s["X0"], s["U"], s["W"], 1, s["T"], rng)
+    idn = H.identify(u, x, s["W"])
+    zon = SystemZonotopes(*(Zonotope(np.asarray(s[k].center), np.asarray(s[k].generators)) for k in ("X0", "U", "X", "W")))
+    ctl = TZDDPC(Data(u, x))
+    ctl.build_zonotopes_theta(zon, theta=Theta(idn["K"], np.zeros_like(A), np.zeros_like(B)))
+    N = 2
+    ctl.horizon, ctl.k0 = N, None
+    e0 = 0.02 * rng.standard_normal((Bn, n)); xb = rng.standard_normal((Bn, N + 1, n)); v = rng.standard_normal((Bn, N, m))
+    out = ctl.literal_tubes(e0, xb, v)
+    Z1 = ctl.ze1_batch(xb[:, 0], e0, v[:, 0])
+    K = idn["K"]
+    for b in sorted({0, Bn // 2, Bn - 1}):
+        Ze1 = idn["MdataK"] * OZ(e0[b], np.zeros((n, 1))) + (idn["Mdelta"] * OZ(np.concatenate([xb[b, 0], v[b, 0]]), np.zeros((n + m, 1))) + s["W"])
+        c, G = np.asarray(Ze1.center), np.asarray(Ze1.generators)
+        sc = 1 + np.abs(G).sum()
+        np.testing.assert_allclose(out["center"][b, 0], e0[b], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(out["rad_x"][b, 0], 0.0, atol=1e-13)
+        np.testing.assert_allclose(out["center"][b, 1], c, rtol=0, atol=1e-12 * sc)
+        np.testing.assert_allclose(out["rad_x"][b, 1], np.abs(G).sum(axis=1), rtol=0, atol=1e-12 * sc)
+        np.testing.assert_allclose(out["rad_u"][b, 1], np.abs(K @ G).sum(axis=1), rtol=0, atol=1e-12 * sc)
+        assert Z1.shape[2] == 1 + G.shape[1]
+        np.testing.assert_allclose(Z1[b, :, 0], c, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(Z1[b, :, 1:], G, rtol=0, atol=1e-13)
