@@ -12,6 +12,9 @@
 
 // TZ_DUP = k (diagnostic builds only, tools/dup_phases.sh): phase k of the fused step is executed TZ_DUP_N more times -- same results, and the
 // slowdown is the cost of that phase in the production schedule (no clocks in the instruction stream)
+#ifndef TZ_RED_INTERLEAVE
+#define TZ_RED_INTERLEAVE 1
+#endif
 #ifndef TZ_DUP
 #define TZ_DUP 0
 #endif
@@ -124,13 +127,17 @@ __device__ inline int tz_tid() {
 #endif
 enum { RED_SUM = 0, RED_MAX = 1, RED_MIN = 2 };
 
+// 64-bit DPP move (two 32-bit halves).  mov_dpp with bound_ctrl instead of update_dpp(0, ...): no `old` operand to initialise -- the
+// compiler materialised the zero with two more moves per call (quad permutes and row rotations read valid lanes only: same values)
 template <int CTRL>
-__device__ inline double tz_dpp_mov(double v) {                          // 64-bit DPP move (two 32-bit halves)
+__device__ inline double tz_dpp_mov(double v) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+// (fmax / fmin put a canonicalising v_max_f64 x, x in front of operands not known to be quiet; the bare instruction through inline
+// assembly removes it -- and costs 36 B/lane more scratch in the kernel's register allocation: 2 % slower overall.  Left as fmax.)
 __device__ inline double tz_readlane(double v, int lane) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
@@ -168,11 +175,36 @@ __device__ inline double tz_wave_reduce(double v) {
 // all threads.  The exchange buffer alternates between red[0..11] and red[16..27] (`par`, toggled here: every thread makes the
 // same sequence of calls), so one barrier per reduction is enough: a buffer is written again only after the barrier of the
 // reduction in between, which no thread reaches before it has read its values of this one.
+// up to three values through the stages of tz_wave_reduce side by side (the compiler keeps three calls one after the other: three
+// dependent chains of six stages in sequence instead of one chain of six stages three wide)
+template <int OP0, int OP1, int OP2, int NV>
+__device__ inline void tz_wave_reduce3(double& a, double& b, double& c) {
+#define TZ_STAGE(CTRL) do { const double ta = tz_dpp_mov<CTRL>(a), tb = (NV > 1) ? tz_dpp_mov<CTRL>(b) : 0.0, tc = (NV > 2) ? tz_dpp_mov<CTRL>(c) : 0.0; \
+    a = tz_op<OP0>(a, ta); if (NV > 1) b = tz_op<OP1>(b, tb); if (NV > 2) c = tz_op<OP2>(c, tc); } while (0)
+  TZ_STAGE(0xB1); TZ_STAGE(0x4E); TZ_STAGE(0x124); TZ_STAGE(0x128);
+#undef TZ_STAGE
+  {
+    const double ta = tz_dpp_mov_rows<0x142, 0xA>((OP0 == RED_SUM) ? 0.0 : a, a), tb = (NV > 1) ? tz_dpp_mov_rows<0x142, 0xA>((OP1 == RED_SUM) ? 0.0 : b, b) : 0.0,
+                 tc = (NV > 2) ? tz_dpp_mov_rows<0x142, 0xA>((OP2 == RED_SUM) ? 0.0 : c, c) : 0.0;
+    a = tz_op<OP0>(a, ta); if (NV > 1) b = tz_op<OP1>(b, tb); if (NV > 2) c = tz_op<OP2>(c, tc);
+  }
+  {
+    const double ta = tz_dpp_mov_rows<0x143, 0xC>((OP0 == RED_SUM) ? 0.0 : a, a), tb = (NV > 1) ? tz_dpp_mov_rows<0x143, 0xC>((OP1 == RED_SUM) ? 0.0 : b, b) : 0.0,
+                 tc = (NV > 2) ? tz_dpp_mov_rows<0x143, 0xC>((OP2 == RED_SUM) ? 0.0 : c, c) : 0.0;
+    a = tz_op<OP0>(a, ta); if (NV > 1) b = tz_op<OP1>(b, tb); if (NV > 2) c = tz_op<OP2>(c, tc);
+  }
+  a = tz_readlane(a, 63); if (NV > 1) b = tz_readlane(b, 63); if (NV > 2) c = tz_readlane(c, 63);
+}
+
 template <int OP0, int OP1, int OP2, int NV = 3>
 __device__ inline void tz_block_reduce3(double& a, double& b, double& c, double* red, int& par) {
+#if TZ_RED_INTERLEAVE
+  tz_wave_reduce3<OP0, OP1, OP2, NV>(a, b, c);
+#else
   a = tz_wave_reduce<OP0>(a);
   if (NV > 1) b = tz_wave_reduce<OP1>(b);
   if (NV > 2) c = tz_wave_reduce<OP2>(c);
+#endif
   const int tt = tz_tid();
   int lane = tt & 63, w = tt >> 6;
   double* rb_ = red + (par ? 16 : 0);
@@ -462,8 +494,8 @@ template <int N>
 __device__ inline double tz_row_ror(double v) {                          // value of lane ((lane & 15) - N) mod 16 of the same row of 16
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   constexpr int ctrl = 0x120 + N;
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, ctrl, 0xf, 0xf, false);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), ctrl, 0xf, 0xf, false);
+  const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, ctrl, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), ctrl, 0xf, 0xf, true);
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
@@ -617,8 +649,8 @@ template <int JJ>
 __device__ inline double tz_quad_bcast(double v) {                     // value of lane (lane & ~3) + JJ, via DPP quad_perm
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   constexpr int ctrl = JJ * 0x55;
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, ctrl, 0xf, 0xf, false);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), ctrl, 0xf, 0xf, false);
+  const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, ctrl, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), ctrl, 0xf, 0xf, true);
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 

@@ -56,8 +56,8 @@ struct TubeParams {
 template <int CTRL>
 __device__ inline double tz_quad_xor(double v) {                       // DPP quad_perm of a double (0xB1: lane^1, 0x4E: lane^2)
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xf, 0xf, true);        // (no `old` operand to initialise)
+  const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 // All nt threads of the workgroup (tid) work on trajectory b.  aL: pmax * n doubles of LDS scratch; th: ntheta doubles (LDS or
