@@ -1049,6 +1049,41 @@ def test_pulley_loop_lives_in_the_reference_envelope(built, gain):
     assert np.all(sim["u"] >= Ui.left_limit - 1e-8) and np.all(sim["u"] <= Ui.right_limit + 1e-8)
 
 
+@pytest.mark.parametrize("run", range(6))
+def test_device_replays_the_reference_pulley_runs(built, run):
+    """The reference's own stored closed-loop runs (examples/results/pulley.xtzddpc.npy + xtzddpc.data.npy -> tests/golden/
+    pulley_reference_vectors.npz: states, and the inputs / disturbances / gain recovered exactly from them, tests/refpulley.py)
+    replayed by the device loop (tz_simulate_batch: N = 2, x0 = 0, 200 steps, the run's disturbances and gain).
+    (A) model identified from OUR data set: states and inputs within the data-set spread of the reference's own six runs, the
+    same affine law u = K x + g with g inside the reference's range;  (B) centre moved inside our Mdata so that the run's nine
+    informative offsets g_0 .. g_8 are reproduced: all 200 stored states and inputs of the run to 2e-7."""
+    from tests import refpulley
+    from tests.test_reference_vectors import product_controller
+    g = refpulley.vectors()
+    K = g["K"][run]
+    noise = refpulley.noise_of(g, run)
+    ctl, (A, B, zon) = product_controller(K, device_build=True)
+    M0 = ctl.Mdata.center.copy()
+    ctl.build_problem(2, common.loss_pulley, common.nocons)                     # examples/2.pulley_sim.py:75,80
+    sim = ctl.simulate_batch(np.zeros((1, 4)), noise, A, B)
+    assert (sim["status"] == 0).all()
+    bx, bu = refpulley.spread_bounds(g, run)
+    assert np.abs(sim["x"][0] - g["x"][run]).max() <= bx
+    assert np.abs(sim["u"][0, :, 0] - g["u"][run]).max() <= bu
+    c, d, res = refpulley.affine_law(sim["x"][0], sim["u"][0, :, 0])
+    assert res <= 1e-7, res
+    np.testing.assert_allclose(c, K, rtol=0, atol=1e-6)
+    assert g["g_star"].min() - 3e-3 <= d <= g["g_star"].max() + 3e-3
+    M, fit = refpulley.fit_admissible_model(M0, K, g["g"][run])
+    assert fit <= 1e-7 and np.all(np.abs(M - M0) <= 0.3 * np.abs(ctl.Mdata.generators).sum(axis=0))
+    ctl2, _ = product_controller(K, M, device_build=True)
+    ctl2.build_problem(2, common.loss_pulley, common.nocons)
+    sim2 = ctl2.simulate_batch(np.zeros((1, 4)), noise, A, B)
+    assert (sim2["status"] == 0).all()
+    dx, du = np.abs(sim2["x"][0] - g["x"][run]).max(), np.abs(sim2["u"][0, :, 0] - g["u"][run]).max()
+    assert dx <= refpulley.TOL_ADMISSIBLE and du <= refpulley.TOL_ADMISSIBLE, (dx, du)
+
+
 @pytest.mark.parametrize("case,T,jitter", [("di_n20", 30, (1.0, 0.5)), ("pulley_n10", 30, (0.3,) * 4), ("dim5_n20", 20, (0.3,) * 5), ("dim5m2q_n20", 20, (0.3,) * 5)])
 def test_calibration_holds_away_from_the_benchmark_start(built, case, T, jitter):
     """The warm-start shift / push and the complementarity target are calibrated at build time on closed loops from the CENTRE of X0
