@@ -66,8 +66,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()                      # no-op when the library is current and was built on this CPU
-        _lib = C.CDLL(LIB)
+        alt = os.environ.get("TZ_ORACLE_LIB")            # a sanitizer build of the same source (tests/test_oracle_sanitizers.py)
+        if not alt:
+            build()                  # no-op when the library is current and was built on this CPU
+        _lib = C.CDLL(alt or LIB)
         _lib.tzo_max_threads.restype = C.c_int
     return _lib
 

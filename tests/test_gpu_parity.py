@@ -1206,6 +1206,21 @@ def test_dense_generators_by_cutting_planes(built):
     boxed, _ = common.gpu_controller("di_n20_k1")                  # the same data set and gain with the boxes of reduce(1): looser tubes
     ob = boxed.solve_batch(x0, e0)
     assert np.all(out["cost"] <= ob["cost"] + 1e-6 * (1 + np.abs(ob["cost"])))
+    # a cut loop that is stopped before it has converged never hands a point that breaks a literal tube row out as solved: a fresh
+    # controller (no cuts yet), no separation round allowed -- every returned status-0 point is literally feasible, the rest is flagged
+    # (solve() raises for them, simulate_batch applies v = 0), and an explicit stopping target / push survives the rebuild
+    fresh = controller(N, k0, mu_factor=1e-4, warm_gain=(0.3, 0.05))
+    v_, xb_, c_, st_, _, _ = fresh._solve_with_cuts(x0, e0, max_rounds=0)
+    assert (st_ != 0).any() and np.all(~np.isfinite(c_[st_ != 0]))
+    okb = st_ == 0
+    if okb.any():
+        tb0 = fresh.literal_tubes(e0[okb], xb_[okb], v_[okb])
+        cx0 = xb_[okb][:, :N] + tb0["center"]; cu0 = v_[okb] + np.einsum("ji,bki->bkj", K, tb0["center"])
+        assert np.all(cx0 + tb0["rad_x"] <= Xi.right_limit + 1e-7) and np.all(cx0 - tb0["rad_x"] >= Xi.left_limit - 1e-7)
+        assert np.all(cu0 + tb0["rad_u"] <= Ui.right_limit + 1e-7) and np.all(cu0 - tb0["rad_u"] >= Ui.left_limit - 1e-7)
+    fresh.solve_batch(x0[:4], e0[:4])                               # now with separation rounds: rebuilds the device problem
+    assert fresh.cut_rounds > 0 and fresh.mu_factor == 1e-4 and (fresh.warm_push_gain, fresh.warm_push_cap) == (0.3, 0.05)
+    assert fresh._native.stopping == (100.0, 1e-4) and fresh._native.warm_push == (1e-8, 0.3, 0.05)      # what the rebuilt device problem was given
     # a second call re-uses the cuts: no further rounds
     ncuts = ctl.num_cuts()
     ctl.solve_batch(x0, e0)

@@ -241,6 +241,13 @@ def test_bench_gpus_flag_spawns_the_ranks_dry_run():
     ln = lines[0]
     assert ln["n_gpus"] == 2 and ln["world_size_read_back"] == 2 and ln["config"]["gathered_rows"] == 66
     assert ln["gather_matches_unsharded"] is True and len(ln["rank_window_ms"]) == 2
+    # rank 0's build-time calibration is what every rank runs with; the line says whether the ranks had agreed on their own
+    assert ln["calibration_identical_across_ranks"] is True and ln["calibration_adopted_from_rank0"] == [3.0, 0.1, 0.01, 1e-5]
+    div = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--batch", "5", "--dry-run", "--backend", "gloo"],
+                         env=dict(env, TZ_DRYRUN_DIVERGE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert div.returncode == 0, div.stderr[-2000:]
+    dl = [json.loads(x) for x in div.stdout.splitlines() if x.startswith("{")][0]
+    assert dl["calibration_identical_across_ranks"] is False and dl["calibration_adopted_from_rank0"][1] == 0.1      # rank 0's gain, not rank 1's 0.2
     # under a launcher whose world size disagrees with --gpus the bench refuses instead of reporting a wrong n_gpus
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run", "--backend", "gloo"],
                          env=dict(env, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"),

@@ -381,6 +381,9 @@ def build_parametric_qp(Ahat, Bhat, CK, DK, Dd, K, W_c, W_G, xl, xu, ul, uu, N: 
     for w, e in loss.soc:
         # ||F u||_2 of the FREE variable u (reference :160, :222: no constraint mentions it) is minimised to 0 independently of
         # everything else -- exact as long as no other term ties u down; a cone on anything else has no QP form
+        if w < 0.0:
+            raise CpliteError("a second-order-cone term with a negative weight is not convex (the reference's is_dcp() check, "
+                              "tzddpc/tzddpc.py:224, rejects it)")
         if w != 0.0 and (need_u or not _only_u_homogeneous(e)):
             raise CpliteError(cplite.SOC_MESSAGE)
     u_var0 = None

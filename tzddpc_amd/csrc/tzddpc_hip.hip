@@ -1058,14 +1058,14 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
     p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg, wgs_per_cu, ttk);
   }
   if (!p->ipm_fn) TZ_FAIL(TZ_ERR_UNSUPPORTED, "this development build (TZ_ONLY_SMALL) carries only the mi <= 256, nz <= 64 kernel");
-  // the tube pass of the fused step keeps |C_K^l e0| (pmax n doubles) in the factor storage, which is free at that point
-  if ((size_t)std::max(d->pmax, 1) * d->n > p->hsize) TZ_FAIL(TZ_ERR_UNSUPPORTED, "pmax * dim_x = %d exceeds the factor storage (%zu doubles) the tube pass borrows", std::max(d->pmax, 1) * d->n, p->hsize);
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
   if (const char* e = getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
   if (p->prof && !TZ_PROFILE) TZ_FAIL(TZ_ERR_INVALID, "TZ_PROF=1 needs the diagnostic build of the library (libtzddpc_hip_prof.so)");
   if (const char* e = getenv("TZ_WARM")) { p->warm_enabled = (e[0] != '0'); }
   if (const char* e = getenv("TZ_FUSE")) { p->fuse_enabled = (e[0] != '0'); }
-  if ((size_t)p->pmax * p->n > p->hsize) p->fuse_enabled = false;   // tube scratch borrows the factor storage
+  // the tube pass of the fused step keeps |C_K^l e0| (pmax n doubles) in the factor storage, which is free at that point: a short-horizon,
+  // large-n problem whose factor is smaller than that runs the four-kernel step instead (tz_tube_kernel has its own scratch)
+  if ((size_t)std::max(p->pmax, 1) * p->n > p->hsize) p->fuse_enabled = false;
   // experiment switches (tools/): the same ranges as the setters (tz_problem_set_stopping / _warm_quiet / _warm_push) -- a value
   // that does not parse or lies outside fails the create call instead of silently changing the solver's accuracy
   {

@@ -48,3 +48,20 @@ def vertex_noise(W_vertices: np.ndarray, first_trajectory: int, count: int, step
         rng = np.random.Generator(np.random.PCG64(seed_base + first_trajectory + i))
         out[i] = W_vertices[rng.integers(len(W_vertices), size=steps)]
     return out
+
+
+def sync_calibration(values, device=None):
+    """Build-time calibration chosen by every rank on its own box (warm-start shift policy, push gain / cap, complementarity
+    factor: short closed loops whose factorisation counts can tie differently on two devices): rank 0's choice is broadcast and
+    returned for every rank to adopt, together with whether all ranks had chosen the same on their own.
+    values: sequence of floats (inf allowed).  -> (rank 0's values as a list of floats, identical_across_ranks: bool)."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if not dist.is_initialized():
+        return [float(v) for v in mine.cpu()], True
+    lead = mine.clone()
+    dist.broadcast(lead, src=0)
+    same = torch.tensor([1.0 if torch.equal(lead, mine) else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+    return [float(v) for v in lead.cpu()], bool(same.item() == 1.0)

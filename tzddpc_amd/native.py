@@ -350,12 +350,14 @@ class Problem:
 
     def set_stopping(self, res_factor: float = 100.0, mu_factor: float = 1e-3):
         check(lib().tz_problem_set_stopping(self._h, float(res_factor), float(mu_factor)), "tz_problem_set_stopping")
+        self.stopping = (float(res_factor), float(mu_factor))          # last values handed to the library (read back by tests)
 
     def set_warm_quiet(self, quiet_steps: int = 16):
         check(lib().tz_problem_set_warm_quiet(self._h, int(quiet_steps)), "tz_problem_set_warm_quiet")
 
     def set_warm_push(self, floor: float = 1e-8, gain: float = 1.0, cap: float = 1e300):
         check(lib().tz_problem_set_warm_push(self._h, float(floor), float(gain), float(min(cap, 1e300))), "tz_problem_set_warm_push")
+        self.warm_push = (float(floor), float(gain), float(cap))
 
     def set_warm_shift(self, policy: int):
         check(lib().tz_problem_set_warm_shift(self._h, int(policy)), "tz_problem_set_warm_shift")

@@ -658,7 +658,7 @@ class TZDDPC(object):
         while True:
             v, xbar, cost, status, iters, active = self._native.solve_batch(xbar0, e0, want_active)
             ok = np.nonzero(status == 0)[0]
-            if ok.size == 0 or self.cut_rounds >= max_rounds:
+            if ok.size == 0:
                 break
             tb = self.literal_tubes(e0[ok], xbar[ok], v[ok])
             cx = xbar[ok][:, :N] + tb["center"]                                   # (Ze[k] + xbar[k]).interval  (:191)
@@ -668,6 +668,12 @@ class TZDDPC(object):
             vu = np.maximum(cu + tb["rad_u"] - uu, ul - (cu - tb["rad_u"])) / su
             bad_x, bad_u = vx > tol, vu > tol
             if not (bad_x.any() or bad_u.any()):
+                break
+            # trajectories whose relaxed solution still violates a literal tube row: never handed out as solved if the loop ends here
+            violating = ok[bad_x.any(axis=(1, 2)) | bad_u.any(axis=(1, 2))]
+            if self.cut_rounds >= max_rounds:
+                status = status.copy(); status[violating] = native.TZ_MAX_ITER
+                cost = cost.copy(); cost[violating] = np.inf
                 break
             zeta = np.concatenate([xbar[ok][:, :N], v[ok]], axis=2)
             added = 0
@@ -691,8 +697,10 @@ class TZDDPC(object):
                         for p in uniq[np.argsort(-cnt)][:per_family]:                  # the most frequent new patterns first
                             if p.tobytes() not in have:
                                 self._cuts.setdefault((int(k), kind, i), []).append(p.copy()); have.add(p.tobytes()); added += 1
-            if added == 0:
-                break                                                                  # nothing new to add: violations are below what the patterns resolve
+            if added == 0:                                                             # every violated row's pattern is a cut already, yet the rows are still
+                status = status.copy(); status[violating] = native.TZ_NUMERICAL        # violated by more than tol: the relaxation was not solved to that accuracy
+                cost = cost.copy(); cost[violating] = np.inf
+                break
             self._rebuild_with_cuts()
             self.cut_rounds += 1
         return v, xbar, cost, status, iters, active
@@ -708,6 +716,8 @@ class TZDDPC(object):
         self._elim, self._scal, self._row_of = info["elim"], info["scal"], info["row_of"]
         self._native.attach_tube_stack(self._gs_tube)
         self._native.set_warm_shift(0)
+        self._native.set_stopping(100.0, float(self.mu_factor))                       # the settings build_problem chose stay with the problem
+        self._native.set_warm_push(1e-8, float(self.warm_push_gain), float(self.warm_push_cap))
         self.problem_full = self.optimization_problem = self._native
 
     def num_cuts(self) -> int:
