@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TZ_ABI_VERSION 3
+#define TZ_ABI_VERSION 4
 
 typedef enum tz_status {
   TZ_OK = 0,
@@ -124,7 +124,19 @@ typedef struct tz_problem_desc {
   const double* rec_c0;
   const double* rec_x0;
   const double* rec_y;
+  /* Plan overrides (0 = the library chooses).  The library picks its code paths from the problem's size and structure; these bits
+   * force the general-size paths on a problem that would qualify for a specialised one -- the parity tests use them to hold the
+   * paths against each other on the same problem.  The release library reads NO environment variables. */
+  int32_t plan_flags;       /* TZ_PLAN_* */
 } tz_problem_desc;
+
+enum {
+  TZ_PLAN_UNFUSED = 1,            /* closed-loop entry points run tube / affine / solve / finish / plant as separate launches */
+  TZ_PLAN_GENERAL_CHOLESKY = 2,   /* nz <= 64: four-wave factorisation and LDS-published solves instead of the one-wave forms */
+  TZ_PLAN_ITEM_GRAM = 4,          /* nz <= 40: item-plan Gram instead of the super-step form */
+  TZ_PLAN_NO_STAIRCASE = 8,       /* nz > 64: keep the caller's variable / row order */
+  TZ_PLAN_ELL_PRODUCTS = 16       /* G x / G'v by the lane-ELL walks even when G is block-Toeplitz over the horizon */
+};
 
 typedef struct tz_problem tz_problem;
 
@@ -313,6 +325,12 @@ int tz_ipm_work_get(tz_problem* p, int64_t* factorizations, int64_t* trajectory_
  * and bytes of the packed constraint patches. */
 int tz_ipm_plan_info(tz_problem* p, int64_t* mfma_gram_per_iter, int64_t* mfma_chol_per_iter,
                      int64_t* mfma_issued_per_iter, int64_t* lds_bytes, int64_t* patch_bytes);
+
+/* The code paths the library chose for this problem (each 0 / 1): one-launch closed-loop step; one-wave factorisation with the
+ * trailing forward substitution (nz <= 64); super-step Gram (nz <= 40); staircase ordering (nz > 64); G x / G'v as block-Toeplitz
+ * convolutions over the horizon.  See tz_problem_desc.plan_flags. */
+int tz_problem_plan_get(tz_problem* p, int32_t* fused, int32_t* one_wave_cholesky, int32_t* superstep_gram, int32_t* staircase,
+                        int32_t* toeplitz);
 
 /* Test hook: copy device-side intermediates of trajectory `b` of the last solve to the host.
  * what: 0 = theta (ntheta), 1 = q (nz), 2 = h (mi)  [0-2: only after tz_solve_batch, the closed-loop launches keep them on chip],

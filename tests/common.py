@@ -93,7 +93,7 @@ def identified_qp(case, seed=25, epigraph="auto", loss=None):
     return ctl, qp, (A, B, zon)
 
 
-def gpu_controller(case, seed=25):
+def gpu_controller(case, seed=25, **solver_kwargs):
     from tzddpc_amd import TZDDPC
     from tzddpc_amd.harness import generate_trajectories, system
     sysname, loss, cons, N, k0 = CASES[case]
@@ -102,9 +102,9 @@ def gpu_controller(case, seed=25):
     ctl = TZDDPC(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, rng))
     ctl.build_zonotopes_theta(zon)
     if k0 is None:
-        ctl.build_problem(N, loss, cons)
+        ctl.build_problem(N, loss, cons, **solver_kwargs)
     else:
-        ctl.build_problem_simplified(k0, N, loss, cons)
+        ctl.build_problem_simplified(k0, N, loss, cons, **solver_kwargs)
     return ctl, (A, B, zon)
 
 

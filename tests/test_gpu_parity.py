@@ -302,16 +302,15 @@ def test_warm_started_closed_loop_equals_cold(built):
     np.testing.assert_allclose(tx.cpu().numpy(), xs[:, -1], atol=1e-6)
 
 
-def test_fused_step_equals_four_kernel_step(built, monkeypatch):
+def test_fused_step_equals_four_kernel_step(built):
     """The one-launch closed-loop step (tube + parameter maps + interior point + recovery + plant inside tz_ipm_kernel) and the
     four-kernel sequence used by tz_solve_batch do the same arithmetic."""
     from tzddpc_amd.dist import vertex_noise
     for case, Bn, T in (("di_n20", 64, 10), ("pulley_n10", 32, 6)):
-        monkeypatch.delenv("TZ_FUSE", raising=False)
+        from tzddpc_amd import native
         fused, (A, B, zon) = common.gpu_controller(case)
-        monkeypatch.setenv("TZ_FUSE", "0")
-        split, _ = common.gpu_controller(case)
-        monkeypatch.delenv("TZ_FUSE", raising=False)
+        split, _ = common.gpu_controller(case, plan_flags=native.TZ_PLAN_UNFUSED)
+        assert fused._native.plan_info()["fused"] and not split._native.plan_info()["fused"]
         noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
         x0 = np.tile(zon.X0.center, (Bn, 1))
         a = fused.simulate_batch(x0, noise, A, B); b = split.simulate_batch(x0, noise, A, B)
@@ -321,19 +320,17 @@ def test_fused_step_equals_four_kernel_step(built, monkeypatch):
         np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-11, atol=1e-11)
 
 
-def test_single_wave_factor_path_equals_four_wave_path(built, monkeypatch):
+def test_single_wave_factor_path_equals_four_wave_path(built):
     """nz <= 64 problems factor on one wave while a second wave runs the forward substitution behind it (column counter in LDS)
-    and use the super-step Gram; TZ_CHOL1=0 / TZ_KSPLIT=0 select the four-wave Cholesky with LDS-published solves and the
+    and use the super-step Gram; plan_flags TZ_PLAN_GENERAL_CHOLESKY | TZ_PLAN_ITEM_GRAM select the four-wave Cholesky with LDS-published solves and the
     item-plan Gram that larger problems use.  Same arithmetic, different order: closed loops agree to rounding."""
     from tzddpc_amd.dist import vertex_noise
     for case, Bn, T in (("di_n20", 96, 12), ("pulley_n10", 48, 8), ("di_n20_k1", 32, 6)):
-        for k in ("TZ_CHOL1", "TZ_KSPLIT"):
-            monkeypatch.delenv(k, raising=False)
+        from tzddpc_amd import native
         fast, (A, B, zon) = common.gpu_controller(case)
-        monkeypatch.setenv("TZ_CHOL1", "0"); monkeypatch.setenv("TZ_KSPLIT", "0")
-        slow, _ = common.gpu_controller(case)
-        for k in ("TZ_CHOL1", "TZ_KSPLIT"):
-            monkeypatch.delenv(k, raising=False)
+        slow, _ = common.gpu_controller(case, plan_flags=native.TZ_PLAN_GENERAL_CHOLESKY | native.TZ_PLAN_ITEM_GRAM)
+        pf, ps = fast._native.plan_info(), slow._native.plan_info()
+        assert pf["chol1"] and pf["ksplit"] and not ps["chol1"] and not ps["ksplit"]
         slow._native.set_warm_shift(fast.warm_shift_policy)      # same policy on both sides (the calibration is per build)
         slow._native.set_warm_push(1e-8, fast.warm_push_gain, fast.warm_push_cap)
         noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
@@ -407,15 +404,13 @@ def test_horizon_sweep_against_c_oracle(built, case):
     np.testing.assert_allclose(dev["cost"], ref["cost"], rtol=1e-7, atol=1e-7)
 
 
-def test_infeasible_trajectories_are_flagged_not_fatal(built, monkeypatch):
+def test_infeasible_trajectories_are_flagged_not_fatal(built):
     """A start outside the feasible set gives that trajectory the sticky status 3 (the reference raises 'Problem is unbounded',
     tzddpc/tzddpc.py:374-375) and leaves the others of the batch untouched; same in the one-launch and the four-kernel shape."""
     from tzddpc_amd.dist import vertex_noise
-    monkeypatch.delenv("TZ_FUSE", raising=False)
+    from tzddpc_amd import native
     fused, (A, B, zon) = common.gpu_controller("di_n20")
-    monkeypatch.setenv("TZ_FUSE", "0")
-    split, _ = common.gpu_controller("di_n20")
-    monkeypatch.delenv("TZ_FUSE", raising=False)
+    split, _ = common.gpu_controller("di_n20", plan_flags=native.TZ_PLAN_UNFUSED)
     Bn, T = 16, 6
     x0 = np.tile(zon.X0.center, (Bn, 1))
     x0[3] = [50.0, 0.0]; x0[11] = [-40.0, 9.0]

@@ -10,20 +10,7 @@
 // row-vector staging buffer, so that four workgroups fit on a CU for the benchmark sizes.
 #pragma once
 
-// TZ_DUP = k (diagnostic builds only, tools/dup_phases.sh): phase k of the fused step is executed TZ_DUP_N more times -- same results, and the
-// slowdown is the cost of that phase in the production schedule (no clocks in the instruction stream)
-#ifndef TZ_RED_INTERLEAVE
-#define TZ_RED_INTERLEAVE 1
-#endif
-#ifndef TZ_DUP
-#define TZ_DUP 0
-#endif
-#ifndef TZ_DUP_N
-#define TZ_DUP_N 1
-#endif
-#ifndef TZ_MINWAVES
 #define TZ_MINWAVES 4
-#endif
 // H lives in LDS as tile rows of quads (4 column tiles); a quad is 4 matrix rows of 16 doubles padded to TZ_QROW = 17 so
 // that neither the MFMA accumulator access (row-major inside the quad) nor the column access of the factorisation and the
 // triangular solves runs into LDS bank conflicts (row stride 16 doubles = 32 banks collides 4- to 8-way).
@@ -107,24 +94,13 @@ __device__ inline int tz_tid() {
 // s_setprio level of the wave that runs a serial stretch of its workgroup (factorisation, triangular solves): four workgroups share
 // a CU and their waves compete for the same SIMD issue slots; putting the wave the other three are waiting for first is worth
 // 3.7 % on the bench problem (2 + 2).  The forward substitution that trails the factorisation is not on the critical path (0).
-#ifndef TZ_PRIO
 #define TZ_PRIO 3
-#endif
-#ifndef TZ_PRIO_SOLVE
 #define TZ_PRIO_SOLVE 3
-#endif
 // The same idea by phase: the short barrier-separated phases between two solves (stopping test passed -> recovery, plant update, tube,
 // maps, warm start) at 2, the element-wise / reduction phases of an iteration at 1, the bulk phases (Gram, G products) at 0:
 // another 3.8 % (A/B on one box: 2 / 1 beats 1 / 0, 1 / 1 and 2 / 2).
-#ifndef TZ_PRIO_ELEM
 #define TZ_PRIO_ELEM 1
-#endif
-#ifndef TZ_PRIO_GLUE
 #define TZ_PRIO_GLUE 2
-#endif
-#ifndef TZ_PRIO_TRAIL
-#define TZ_PRIO_TRAIL 0
-#endif
 enum { RED_SUM = 0, RED_MAX = 1, RED_MIN = 2 };
 
 // 64-bit DPP move (two 32-bit halves).  mov_dpp with bound_ctrl instead of update_dpp(0, ...): no `old` operand to initialise -- the
@@ -198,13 +174,7 @@ __device__ inline void tz_wave_reduce3(double& a, double& b, double& c) {
 
 template <int OP0, int OP1, int OP2, int NV = 3>
 __device__ inline void tz_block_reduce3(double& a, double& b, double& c, double* red, int& par) {
-#if TZ_RED_INTERLEAVE
   tz_wave_reduce3<OP0, OP1, OP2, NV>(a, b, c);
-#else
-  a = tz_wave_reduce<OP0>(a);
-  if (NV > 1) b = tz_wave_reduce<OP1>(b);
-  if (NV > 2) c = tz_wave_reduce<OP2>(c);
-#endif
   const int tt = tz_tid();
   int lane = tt & 63, w = tt >> 6;
   double* rb_ = red + (par ? 16 : 0);
@@ -264,50 +234,13 @@ __device__ inline double tz_gemvT_get3(const double* part, int nzp, int c) {
 }
 
 // out[k] = (G in)_r for the rows r = t + 256 k this thread owns; `in` (nz entries) and pl (eg.VL doubles) in LDS.
-// One lane's walk over its L (value, index) pairs, NL lanes apart.  DEEP: sixteen pairs requested before the first is used instead of
-// four.  Measured on the problems with long walks (DI N=40: 72 pairs per lane in G'v; 5-dim N=20): 10-35 % SLOWER -- the products are
-// bound by the rate at which the lines arrive from L2, not by the round trips -- so it stays off (TZ_ELL_DEEP).
-#ifndef TZ_ELL_DEEP
-#define TZ_ELL_DEEP false
-#endif
-template <bool DEEP>
-__device__ inline double tz_ell_walk(const double* val, const unsigned short* idx, int L, int NL, const double* in) {
-  double a0 = 0.0, a1 = 0.0;
-  int e = 0;
-  if (DEEP) {
-    for (; e + 15 < L; e += 16) {
-      double x[16]; int i[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) { x[u] = val[(size_t)(e + u) * NL]; i[u] = idx[(size_t)(e + u) * NL]; }
-#pragma unroll
-      for (int u = 0; u < 16; u += 2) { a0 += x[u] * in[i[u]]; a1 += x[u + 1] * in[i[u + 1]]; }
-    }
-    if (e < L) {                                     // tail: the same sixteen requests, clamped to the last pair and zeroed
-      double x[16]; int i[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) { const int ee = min(e + u, L - 1); x[u] = val[(size_t)ee * NL]; i[u] = idx[(size_t)ee * NL]; }
-#pragma unroll
-      for (int u = 0; u < 16; u += 2) { a0 += (e + u < L ? x[u] : 0.0) * in[i[u]]; a1 += (e + u + 1 < L ? x[u + 1] : 0.0) * in[i[u + 1]]; }
-    }
-    return a0 + a1;
-  }
-  for (; e + 3 < L; e += 4) {
-    const double x0 = val[(size_t)e * NL], x1 = val[(size_t)(e + 1) * NL], x2 = val[(size_t)(e + 2) * NL], x3 = val[(size_t)(e + 3) * NL];
-    const int i0 = idx[(size_t)e * NL], i1 = idx[(size_t)(e + 1) * NL], i2 = idx[(size_t)(e + 2) * NL], i3 = idx[(size_t)(e + 3) * NL];
-    a0 += x0 * in[i0]; a1 += x1 * in[i1]; a0 += x2 * in[i2]; a1 += x3 * in[i3];
-  }
-  for (; e < L; ++e) a0 += val[(size_t)e * NL] * in[idx[(size_t)e * NL]];
-  return a0 + a1;
-}
-
-template <int MAXR, bool DEEP = false>
+template <int MAXR>
 __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double* pl, const int (&rseg)[MAXR], double (&out)[MAXR]) {
   const int t = tz_tid(), L = p.eg.L;
   __syncthreads();                                   // pl may still be read by the owners of the previous product
   for (int v0 = 0; v0 < p.eg.VL; v0 += TZ_THREADS) {
     const double* val = p.eg.val + (size_t)v0 * L + t;
     const unsigned short* idx = p.eg.idx + (size_t)v0 * L + t;
-    if (DEEP) { pl[v0 + t] = tz_ell_walk<true>(val, idx, L, TZ_THREADS, in); continue; }
     double a0 = 0.0, a1 = 0.0;
     int e = 0;
     for (; e + 3 < L; e += 4) {
@@ -318,24 +251,6 @@ __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double*
     for (; e < L; ++e) a0 += val[(size_t)e * TZ_THREADS] * in[idx[(size_t)e * TZ_THREADS]];
     pl[v0 + t] = a0 + a1;
   }
-#if TZ_DUP == 20
-  for (int dup = 0; dup < TZ_DUP_N; ++dup) {
-    asm volatile("" ::: "memory");
-    for (int v0 = 0; v0 < p.eg.VL; v0 += TZ_THREADS) {
-      const double* val = p.eg.val + (size_t)v0 * L + t;
-      const unsigned short* idx = p.eg.idx + (size_t)v0 * L + t;
-      double a0 = 0.0, a1 = 0.0;
-      int e = 0;
-      for (; e + 3 < L; e += 4) {
-        const double x0 = val[(size_t)e * TZ_THREADS], x1 = val[(size_t)(e + 1) * TZ_THREADS], x2 = val[(size_t)(e + 2) * TZ_THREADS], x3 = val[(size_t)(e + 3) * TZ_THREADS];
-        const int i0 = idx[(size_t)e * TZ_THREADS], i1 = idx[(size_t)(e + 1) * TZ_THREADS], i2 = idx[(size_t)(e + 2) * TZ_THREADS], i3 = idx[(size_t)(e + 3) * TZ_THREADS];
-        a0 += x0 * in[i0]; a1 += x1 * in[i1]; a0 += x2 * in[i2]; a1 += x3 * in[i3];
-      }
-      for (; e < L; ++e) a0 += val[(size_t)e * TZ_THREADS] * in[idx[(size_t)e * TZ_THREADS]];
-      pl[v0 + t] = a0 + a1;
-    }
-  }
-#endif
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < MAXR; ++k) {
@@ -346,32 +261,16 @@ __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double*
     for (int j = 0; j < cnt; ++j) a += pl[first + j];
     out[k] = a;
   }
-#if TZ_DUP == 21
-  for (int dup = 0; dup < TZ_DUP_N; ++dup) {
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < MAXR; ++k) {
-      double a = 0.0;
-      int sg = rseg[k];
-      asm volatile("" : "+v"(sg));
-      const int first = sg & 0xffff, cnt = sg >> 16;
-      for (int j = 0; j < cnt; ++j) a += pl[first + j];
-      out[k] = a;
-    }
-  }
-#endif
 }
 
 // Partial sums of G'in by the 192 threads of waves 1-3 (the caller keeps wave 0 out); `in` (mi entries), pl (et.VL doubles) in
 // LDS.  After the next workgroup barrier tz_ell_colsum(pl, cseg) is column c's value for the thread holding cseg = et.seg[c].
-template <bool DEEP = false>
 __device__ inline void tz_ell_gemvT_part(const IpmParams& p, const double* in, double* pl) {
   constexpr int NL = TZ_THREADS - 64;
   const int l = tz_tid() - 64, L = p.et.L;
   for (int v0 = 0; v0 < p.et.VL; v0 += NL) {
     const double* val = p.et.val + (size_t)v0 * L + l;
     const unsigned short* idx = p.et.idx + (size_t)v0 * L + l;
-    if (DEEP) { pl[v0 + l] = tz_ell_walk<true>(val, idx, L, NL, in); continue; }
     double a0 = 0.0, a1 = 0.0;
     int e = 0;
     for (; e + 3 < L; e += 4) {
@@ -481,9 +380,6 @@ __device__ inline void tz_form_H(const IpmParams& p, double* Hq, const double* w
 // range [R0, R1), wave&1 the even / odd super-steps; the partial sums are folded over blk with DPP row rotations and the
 // two halves added through LDS in a fixed order (deterministic).
 #define TZ_KS_TZ 10
-#ifndef TZ_GRAM_MASK
-#define TZ_GRAM_MASK 1
-#endif
 __device__ inline double tz_sel4(int blk, double v0, double v1, double v2, double v3) {
   const double a = (blk & 1) ? v1 : v0, b = (blk & 1) ? v3 : v2;
   return (blk & 2) ? b : a;
@@ -499,8 +395,7 @@ __device__ inline double tz_row_ror(double v) {                          // valu
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// DRY (diagnostic builds, TZ_DUP = 11 / 12): 1 = the operand loop alone, 2 = the fold alone; results kept alive, nothing stored
-template <int R0, int R1, int DRY = 0>
+template <int R0, int R1>
 __device__ inline void tz_gram_rows(const IpmParams& p, double* Hq, const double* Pq, const double* wv, const int* sm, const int h, unsigned long long* pacc) {
   unsigned long long tq0 = pacc ? __builtin_amdgcn_s_memtime() : 0;
   const int lane = tz_tid() & 63;
@@ -515,22 +410,14 @@ __device__ inline void tz_gram_rows(const IpmParams& p, double* Hq, const double
     for (int J = 0; J < R1; ++J) acc[a][J] = 0.0;
   auto load = [&](int s, TzGStage& st) {
     int kc = 4 * s + blk; kc = (kc < Kc) ? kc : Kc;                      // patch row Kc is all zero, wv[4 Kc + k] = 0
-#if TZ_GRAM_MASK
     st.m = sm[s < S ? s : S];                                            // LDS copy of smask, smask[S] = 0 (made scalar at its use)
-#else
-    st.m = 0x3ff; (void)sm;
-#endif
     st.w = wv[4 * kc + k];
     const char* prow = gp + (size_t)kc * rowbytes;
 #pragma unroll
     for (int J = 0; J < R1; ++J) st.v[J] = tz_ld_pinned((const double*)(prow + (unsigned)(J < Tz ? J : Tz) * 128u));   // tile Tz is zero
   };
   auto mma = [&](const TzGStage& st) {
-#if TZ_GRAM_MASK
     const int m = __builtin_amdgcn_readfirstlane(st.m);
-#else
-    const int m = 0x3ff;
-#endif
 #pragma unroll
     for (int I = R0; I < R1; ++I) {
       if ((m >> I) & 1) {
@@ -542,19 +429,10 @@ __device__ inline void tz_gram_rows(const IpmParams& p, double* Hq, const double
     }
   };
   TzGStage s0, s1;
-  if (DRY != 2) {
   load(h, s0);
   for (int s = h; s < S; s += 4) {
     load(s + 2, s1); mma(s0);
     load(s + 4, s0); mma(s1);
-  }
-  }
-  if (DRY != 0) {
-#pragma unroll
-    for (int a = 0; a < R1 - R0; ++a)
-#pragma unroll
-      for (int J = 0; J < R1; ++J) asm volatile("" : "+v"(acc[a][J]));
-    if (DRY == 1) return;
   }
   if (pacc) { unsigned long long t1 = __builtin_amdgcn_s_memtime(); pacc[PH_GRAM_LOOP] += t1 - tq0; tq0 = t1; }
   // fold the four patch rows (blk) of every tile with two row rotations (every lane of a row of 16 then holds the tile sum),
@@ -566,13 +444,6 @@ __device__ inline void tz_gram_rows(const IpmParams& p, double* Hq, const double
 #pragma unroll
     for (int J = 0; J < R1; ++J)
       if (J <= a + R0) { double v = acc[a][J]; v += tz_row_ror<4>(v); v += tz_row_ror<8>(v); acc[a][J] = v; }
-  if (DRY == 2) {
-#pragma unroll
-    for (int a = 0; a < R1 - R0; ++a)
-#pragma unroll
-      for (int J = 0; J < R1; ++J) asm volatile("" :: "v"(acc[a][J]));
-    return;
-  }
   for (int hh = 0; hh < 2; ++hh) {
     if (h == hh) {
 #pragma unroll
@@ -595,13 +466,6 @@ __device__ inline void tz_gram_rows(const IpmParams& p, double* Hq, const double
   }
 }
 
-template <int DRY = 0>
-__device__ inline void tz_form_H_ksplit_dry(const IpmParams& p, double* Hq, const double* Pq, const double* wv, const int* sm) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = wave >> 1, h = wave & 1;
-  if (p.Tz > 7) { if (g == 0) tz_gram_rows<0, 7, DRY>(p, Hq, Pq, wv, sm, h, nullptr); else tz_gram_rows<7, 10, DRY>(p, Hq, Pq, wv, sm, h, nullptr); }
-  else          { if (g == 0) tz_gram_rows<0, 5, DRY>(p, Hq, Pq, wv, sm, h, nullptr); else tz_gram_rows<5, 7, DRY>(p, Hq, Pq, wv, sm, h, nullptr); }
-}
 __device__ inline void tz_form_H_ksplit(const IpmParams& p, double* Hq, const double* Pq, const double* wv, const int* sm, unsigned long long* pacc) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = wave >> 1, h = wave & 1;
@@ -614,9 +478,6 @@ __device__ inline void tz_gram(const IpmParams& p, double* Hq, const double* Pq,
   else tz_form_H(p, Hq, wv, kl);
 }
 
-#ifndef TZ_RSQ_STEPS
-#define TZ_RSQ_STEPS 1
-#endif
 // sqrt(d) and 1/sqrt(d) from v_rsq_f64 + TZ_RSQ_STEPS coupled Newton steps and one residual correction each (deterministic; no
 // f64 divide / sqrt sequences).  One step takes the ~2^-26 seed to ~2^-51, the corrections to the last bit or two.
 __device__ inline void tz_sqrt_rsqrt(double d, double& sq, double& rs) {
@@ -624,10 +485,6 @@ __device__ inline void tz_sqrt_rsqrt(double d, double& sq, double& rs) {
   double g = d * y, h = 0.5 * y;
   double r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
-#if TZ_RSQ_STEPS > 1
-  r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
-#endif
   const double e = __builtin_fma(-g, g, d);
   g = __builtin_fma(e, h, g);
   double inv = h + h;
@@ -914,9 +771,7 @@ __device__ inline void tz_chol_solve(const IpmParams& p, const double* Hq, const
 __device__ inline void tz_chol_solve_wave(const IpmParams& p, const double* Hq, const double* dinv, const double* rhs, double* out, bool bwd_only = false) {
   const int tt = tz_tid();
   if (tt >= 64) return;
-#if TZ_PRIO_SOLVE
   __builtin_amdgcn_s_setprio(TZ_PRIO_SOLVE);
-#endif
   const int Tz = p.Tz, nzp = p.nzp;
   const int t = tt, jq = t & 3, tq = t >> 2;
   double rv = (t < nzp) ? rhs[t] : 0.0;
@@ -963,9 +818,7 @@ __device__ inline void tz_chol_solve_wave(const IpmParams& p, const double* Hq, 
     if (I - 1 >= 0) fwd_step(I - 1, mB, lB);
   }
   if (t < nzp) out[t] = rv;
-#if TZ_PRIO_SOLVE
   __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
 // Forward substitution L y = r by ONE wave (any: lane = row) while another wave is still factoring: step I starts when the
@@ -996,21 +849,11 @@ __device__ inline bool tz_fwd_trailing(const IpmParams& p, const double* Hq, con
 #include "tz_tt.hip.h"
 // unit size of the blocked Gram by register budget (MINW = workgroups per CU the variant is compiled for: 2 -> 256 registers,
 // 1 -> 512) and super-steps in flight; the host plans its units with the same size (tzddpc_hip.hip)
-#ifndef TZ_TT_NST
 #define TZ_TT_NST 4
-#endif
 #define TZ_TT_GU(minw) ((minw) >= 2 ? 6 : 8)
 // triangular solves of the tile-triangle class: by 16 x 16 diagonal blocks with explicit block inverses (default) or tile by tile
-#ifndef TZ_TT_BLOCK_SOLVE
-#define TZ_TT_BLOCK_SOLVE 1
-#endif
-#if TZ_TT_BLOCK_SOLVE
 #define TZ_TT_AFTER_CHOL(p, H, dinv) do { tz_tt_block_inverse(p, H, dinv); __syncthreads(); } while (0)
 #define TZ_TT_SOLVE(p, H, dinv, rhs, ybuf, out) tz_chol_solve_blk(p, H, rhs, ybuf, out)
-#else
-#define TZ_TT_AFTER_CHOL(p, H, dinv) do { } while (0)
-#define TZ_TT_SOLVE(p, H, dinv, rhs, ybuf, out) tz_chol_solve_tt(p, H, dinv, rhs, ybuf, out)
-#endif
 
 // LDS footprint in doubles (host mirrors this in tzddpc_hip.hip).  hsize: doubles of the factor storage -- nquads * TZ_QSTR in the
 // quad layout (nz <= 64), ntile * TS in the tile-triangle layout; the latter keeps 16 more doubles behind dinv for the factor of
@@ -1166,9 +1009,6 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
       const int* pwl = (const int*)(Tt + (F.tube.pmax > 0 ? F.tube.pmax : 1) * (n + m) * n + 3 * n * n + 2 * n * m + n + n * nv + nv);
       if (n == 2 && m == 1) tz_tube_block<2, 1>(F.tube, tbl, Tt, pwl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS);
       else tz_tube_block(F.tube, tbl, Tt, pwl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS);
-#if TZ_DUP == 1
-      for (int dup = 0; dup < TZ_DUP_N; ++dup) { __syncthreads(); tz_tube_block<2, 1>(F.tube, tbl, Tt, pwl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS); }
-#endif
     }
     __syncthreads();
     TZ_STAMP(PH_TUBE);
@@ -1181,14 +1021,6 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     }
     if (bad) flag[1] = 1;
     TZ_ROWS(k, r) TZ_SET_H(k, r, csr_row(F.hmap, r, thl));
-#if TZ_DUP == 2
-    for (int dup = 0; dup < TZ_DUP_N; ++dup) {
-      asm volatile("" ::: "memory");
-      for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? csr_row(F.qmap, c, thl) : 0.0; }
-      for (int r = t; r < F.npar; r += TZ_THREADS) { const double v = csr_row(F.parmap, r, thl); if (!(v >= F.par_lo[r] - 1e-9) || !(v <= F.par_hi[r] + 1e-9)) flag[1] = 1; }
-      TZ_ROWS(k, r) TZ_SET_H(k, r, csr_row(F.hmap, r, thl));
-    }
-#endif
   } else {
     for (int c = t; c < nzp; c += TZ_THREADS) qv[c] = (c < nz) ? pk.q[(size_t)b * nz + c] : 0.0;
     TZ_ROWS(k, r) TZ_SET_H(k, r, pk.h[(size_t)b * mi + r]);
@@ -1211,18 +1043,8 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     }
     TZ_STAMP(PH_RD_A);
     if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part);     // P x by wave 0 (stays in `part` for the objective)
-    else tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);                                   // G'lambda by waves 1-3
+    else tz_ell_gemvT_part(p, vin, pl);                                   // G'lambda by waves 1-3
     __syncthreads();
-#if TZ_DUP == 5
-    for (int dup = 0; dup < TZ_DUP_N; ++dup) {
-      asm volatile("" ::: "memory");
-      if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part); else tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
-      __syncthreads();
-    }
-#endif
-#if TZ_DUP == 6
-    for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); __syncthreads(); }
-#endif
     TZ_STAMP(PH_RD_B);
     double e1 = 0.0;
     if (nzp <= 64) {
@@ -1283,18 +1105,12 @@ retry_solve:
     }
     // G x of the starting point: inside a launch gx_ still holds it (it followed x through the iterations of the previous
     // step); it is formed afresh every eighth step so that rounding does not accumulate along a trajectory
-    if (src != 2 || (step & 7) == 0 || retried || shifted) { tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
-#if TZ_DUP == 3
-    for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
-#endif
+    if (src != 2 || (step & 7) == 0 || retried || shifted) { tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
     TZ_STAMP(PH_WARM_A);
     double viol = 0.0;
     TZ_ROWS(k, r) { const double hv = TZ_H(k, r); viol = fmax(viol, TZ_GX(k, r) - hv); sch = fmax(sch, fabs(hv)); }
     for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
     tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red, rpar);      // also the scales of the stopping test
-#if TZ_DUP == 4
-    for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" : "+v"(viol), "+v"(scq), "+v"(sch)); tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red, rpar); }
-#endif
     TZ_STAMP(PH_WARM_B);
     const double sig = fmin(fmax(pk.warm_floor, pk.warm_gain * viol), pk.warm_cap);
     const double sig2 = sig * sig;
@@ -1311,7 +1127,7 @@ retry_solve:
     __syncthreads();
     TZ_ROWS(k, r) vin[r] = TZ_H(k, r);
     __syncthreads();
-    if (!wave0) tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
+    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
     __syncthreads();
     if (t < nzp) r1v[t] = (t < nz) ? tz_ell_colsum(pl, cseg) - qv[t] : 0.0;
     __syncthreads();
@@ -1321,7 +1137,7 @@ retry_solve:
     else okf = tz_cholesky(p, Hq, dinv, flag);
     if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, xv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
     }
-    tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, xv, pl, rseg_, gx_);
+    tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
     if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; }
   }
   if (!warm) {
@@ -1345,13 +1161,9 @@ retry_solve:
   // diagonal-shift level of this solve (0: none), raised when a factorisation breaks down; the cold retry of a failed solve starts at
   // level 2 (1e-6): a breakdown the pivot test does not see (tiny positive pivots, a garbage step) is what made the first one fail
   int rlev = retried ? 2 : 0;
-#if TZ_PRIO_GLUE
   __builtin_amdgcn_s_setprio(0);
-#endif
   for (it = 0; it < pk.max_iter && status == 1; ++it) {
-#if TZ_PRIO_ELEM
     __builtin_amdgcn_s_setprio(TZ_PRIO_ELEM);
-#endif
     TZ_FRESH_T();
     // the tolerances and step-rule constants are read from the kernel-argument segment where they are used (scalar loads) instead
     // of living in -- and being spilled from -- two dozen scalar registers for the whole kernel
@@ -1394,17 +1206,9 @@ retry_solve:
     // rest of the solve -- and the iteration is repeated from the same point (it counts as an iteration).  A shifted H only damps
     // the Newton step; the residuals are always exact.  `rlev` is uniform (scalar register); level 0, the normal case, costs one
     // scalar branch.
-#if TZ_PRIO_ELEM
     __builtin_amdgcn_s_setprio(0);
-#endif
     if constexpr (TT) tz_gram_tt<TZ_TT_GU(MINW), TZ_TT_NST>(p, Hq, vin, (PROF && t == 0) ? acc_ph : nullptr); else tz_gram(p, Hq, Pq, vin, kl, (PROF && t == 0) ? acc_ph : nullptr);
     __syncthreads();
-#if TZ_DUP == 11 || TZ_DUP == 12
-    if constexpr (!TT) for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_form_H_ksplit_dry<TZ_DUP - 10>(p, Hq, Pq, vin, kl); }
-#endif
-#if TZ_DUP == 7
-    if constexpr (!TT) for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_gram(p, Hq, Pq, vin, kl, nullptr); __syncthreads(); }
-#endif
     TZ_STAMP(PH_FORM);
     TZ_FRESH_T();
     if (rlev != 0) {
@@ -1421,15 +1225,11 @@ retry_solve:
     __syncthreads();
     if (!TT && p.chol1) {
       if (wave0) {
-#if TZ_PRIO
         __builtin_amdgcn_s_setprio(TZ_PRIO);                 // the serial stretch of this workgroup: ahead of the co-resident waves
-#endif
         tz_cholesky_wave(p, Hq, dinv, flag, flag + 2);
-#if TZ_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
       } else {
-        tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
+        tz_ell_gemvT_part(p, vin, pl);
         tz_gemvT_partial<NCG, 1, 3>(p.P, p.nP, nzp, xv, part2);
         // the three waves meet on a counter (wave 0 is busy factoring); wave 1 then assembles the right-hand side and runs the
         // forward substitution one tile column behind the factorisation
@@ -1444,13 +1244,7 @@ retry_solve:
             rdv[c] = pxq;                                                 // P x + q, used again by the corrector
             rv = (c < nz) ? -pxq - tz_ell_colsum(pl, cseg) : 0.0;
           }
-#if TZ_PRIO_TRAIL
-          __builtin_amdgcn_s_setprio(TZ_PRIO_TRAIL);
-#endif
           ok1 = tz_fwd_trailing(p, Hq, dinv, rv, flag + 2, tmpz) && ok1;
-#if TZ_PRIO_TRAIL
-          __builtin_amdgcn_s_setprio(0);
-#endif
           if (!ok1 && c == 0) flag[0] = 3;
         }
       }
@@ -1460,7 +1254,7 @@ retry_solve:
       TZ_STAMP(PH_CHOL);
     } else {
       if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part2);
-      else tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
+      else tz_ell_gemvT_part(p, vin, pl);
       __syncthreads();
       for (int c = t; c < nzp; c += TZ_THREADS) {
         const double pxq = (c < nz) ? part2[c] + qv[c] : 0.0;
@@ -1485,18 +1279,10 @@ retry_solve:
     if constexpr (TT) TZ_TT_SOLVE(p, Hq, dinv, r1v, tmpz, dxv);
     else if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, have_y ? tmpz : r1v, dxv, have_y); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
-#if TZ_DUP == 9
-    if constexpr (!TT) for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_chol_solve_wave(p, Hq, dinv, have_y ? tmpz : r1v, dxv, have_y); __syncthreads(); }
-#endif
     TZ_STAMP(PH_SOLVE);
-    tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, dxv, pl, rseg_, g_);
-#if TZ_DUP == 10
-    for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, dxv, pl, rseg_, g_); }
-#endif
+    tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
     TZ_STAMP(PH_GEMV);
-#if TZ_PRIO_ELEM
     __builtin_amdgcn_s_setprio(TZ_PRIO_ELEM);
-#endif
     // step to the boundary: alpha = 1 / max(1, max_i(-dv_i / v_i))
     TZ_FRESH_T();
     double mp = 0.0, md = 0.0, z4 = 0;
@@ -1540,10 +1326,8 @@ retry_solve:
     }
     __syncthreads();
     TZ_STAMP(PH_ELEM);
-#if TZ_PRIO_ELEM
     __builtin_amdgcn_s_setprio(0);
-#endif
-    if (!wave0) tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
+    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
     __syncthreads();
     for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? -rdv[c] - tz_ell_colsum(pl, cseg) : 0.0;
     __syncthreads();
@@ -1551,15 +1335,10 @@ retry_solve:
     if constexpr (TT) TZ_TT_SOLVE(p, Hq, dinv, r1v, tmpz, dxv);
     else if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, dxv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
-#if TZ_DUP == 8
-    if constexpr (!TT) for (int dup = 0; dup < TZ_DUP_N; ++dup) { asm volatile("" ::: "memory"); tz_chol_solve_wave(p, Hq, dinv, r1v, dxv); __syncthreads(); }
-#endif
     TZ_STAMP(PH_SOLVE);
-    tz_ell_gemv<MAXR, TZ_ELL_DEEP>(p, dxv, pl, rseg_, g_);
+    tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
     TZ_STAMP(PH_GEMV);
-#if TZ_PRIO_ELEM
     __builtin_amdgcn_s_setprio(TZ_PRIO_ELEM);
-#endif
     double ms = 0.0, ml = 0.0, z3 = 0;
     TZ_ROWS(k, r) {
       const double rc = ds_[k];
@@ -1576,9 +1355,7 @@ retry_solve:
     TZ_ROWS(k, r) { s_[k] += alpha * ds_[k]; l_[k] += alpha * dl_[k]; TZ_ADD_GX(k, r, alpha * g_[k]); }
     __syncthreads();
   }
-#if TZ_PRIO_GLUE
   __builtin_amdgcn_s_setprio(TZ_PRIO_GLUE);       // stopping test done: recovery, plant update, tube, maps and warm start of the next step are short
-#endif                                            // barrier-separated phases -- ahead of the bulk phases of the co-resident workgroups
   TZ_FRESH_T();
   work_f = __builtin_amdgcn_readfirstlane(work_f + it + ((warm || skip) ? 0 : 1));
   if (status != 0 && !skip && attempt == 0) {
@@ -1604,7 +1381,7 @@ retry_solve:
     double hy = 0.0;
     TZ_ROWS(k, r) { const double y = lm_ok ? l_[k] * il : 0.0; vin[r] = y; hy += TZ_H(k, r) * y; }
     __syncthreads();
-    if (!wave0) tz_ell_gemvT_part<TZ_ELL_DEEP>(p, vin, pl);
+    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
     __syncthreads();
     double gmax = fabs(tz_ell_colsum(pl, cseg));
     tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM, 2>(gmax, hy, z2, red, rpar);
@@ -1686,21 +1463,6 @@ retry_solve:
       }
     }
     __syncthreads();
-#if TZ_DUP == 15
-    for (int dup = 0; dup < TZ_DUP_N; ++dup) {
-      asm volatile("" ::: "memory");
-      for (int c = t; c < nv; c += TZ_THREADS) dxv[c] = cDz[c] * xv[F.fin.vpos ? F.fin.vpos[c] : c];
-      __syncthreads();
-      const int ln = t & 63;
-      for (int i = __builtin_amdgcn_readfirstlane(t >> 6); i < n; i += TZ_NWAVES) {
-        double a = (ln < n) ? cPhi[i * n + ln] * x0[ln] : 0.0;
-        for (int c = ln; c < nv; c += 64) a += cGam[i * nv + c] * dxv[c];
-        a = tz_wave_reduce<RED_SUM>(a);
-        if (ln == 0) tmpz[i] = a;
-      }
-      __syncthreads();
-    }
-#endif
     TZ_STAMP(PH_EPI_B);
     if (t < 64) {
       const PlantParams& Q = F.plant;

@@ -265,9 +265,7 @@ __device__ inline bool tz_cholesky_tt(const IpmParams& p, double* Ht, double* di
   for (int pp = 0; pp < Tz; ++pp) {
     unsigned long long tc0 = pacc ? __builtin_amdgcn_s_memtime() : 0;
     if (wave == 0) {
-#if TZ_PRIO
       __builtin_amdgcn_s_setprio(TZ_PRIO);
-#endif
       const double* d = Ht + (tz_tri(pp) + pp) * TS;
       double a00 = d[0], a10 = d[4], a11 = d[5], a20 = d[8], a21 = d[9], a22 = d[10], a30 = d[12], a31 = d[13], a32 = d[14], a33 = d[15];
       if (pp > 0) {                                                        // minus X X' with X = L(pp, pp - 1)
@@ -310,9 +308,7 @@ __device__ inline bool tz_cholesky_tt(const IpmParams& p, double* Ht, double* di
         dfac[0] = l10; dfac[1] = l20; dfac[2] = l21; dfac[3] = l30; dfac[4] = l31; dfac[5] = l32;
         dfac[6] = i00; dfac[7] = i11; dfac[8] = i22; dfac[9] = i33;
       }
-#if TZ_PRIO
       __builtin_amdgcn_s_setprio(0);
-#endif
     } else if (pp > 0) {
 #if TZ_PROFILE
       unsigned long long tw0 = __builtin_amdgcn_s_memtime();

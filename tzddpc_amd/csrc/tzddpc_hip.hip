@@ -3,6 +3,18 @@
 // kernels of tz_kernels.hip.h on one HIP stream.  No torch types, no CPU compute fallback: every
 // numeric result comes out of a kernel.
 #include "tz_kernels.hip.h"
+
+// Experiment switches (tools/*.sh, tools/*.py) are read from the environment by the DIAGNOSTIC build only (libtzddpc_hip_prof.so,
+// -DTZ_PROFILE=1); the release library reads no environment variable: what a caller may choose goes through tz_problem_desc
+// (plan_flags) and the tz_problem_set_* entry points.
+static inline const char* tz_dev_getenv(const char* name) {
+#if TZ_PROFILE
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 #include "../../include/tzddpc.h"
 
 #include <algorithm>
@@ -191,7 +203,9 @@ struct tz_problem {
   std::vector<int> permc, permr;   // device variable / row i is the caller's permc[i] / permr[i] (empty = identity)
   bool chol1 = false;          // single-wave Cholesky overlapped with the predictor's G' product (Tz <= 16; TZ_CHOL1=0 disables)
   bool ksplit = false;         // Gram by k-split (Tz <= TZ_KS_TZ; TZ_KSPLIT=0 keeps the item plan)
-  bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_FUSE=0: four kernels per step, same arithmetic)
+  bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_PLAN_UNFUSED: four kernels per step, same arithmetic)
+  bool staircase = false;      // tile-triangle class: variables in time order, rows by last non-zero column (library-internal)
+  bool toeplitz = false;       // G x / G'v as block-Toeplitz convolutions over the horizon (tz_conv.hip.h)
   struct tz_genstack* tube_stack = nullptr;   // literal problems: decision-independent generators, evaluated per solve (not owned)
   DevBuf<double> ts_zeta, ts_c, ts_rx, ts_ru;  int ts_cap = 0;
   int maxr = 1, ncg = 1;
@@ -506,11 +520,11 @@ int tz_genstack_create(int device, const tz_genstack_desc* d, tz_genstack** out)
   g->nchunk = (int)chunks.size();
   // matrix-core layout of the sorted stack (dimensions with a compiled instance): per group of 4 generators (a chunk is padded
   // with zero generators) [component c < P][generator i < 4][inner k < P] of Mext = [M; K M], then [c][i] of m0ext = [m0; K m0]
-  g->mfma = (p >= 3 && p <= 7) && !getenv("TZ_GS_VALU");
+  g->mfma = (p >= 3 && p <= 7) && !tz_dev_getenv("TZ_GS_VALU");
   // one input (the reference's systems): a second copy of the stack holds only the n rows [m0 | M] -- 1 / (n + 1) fewer bytes and matrix
   // instructions -- and K g is formed in the kernel; it serves every batch except 33 .. 64 trajectories, where the extra vector
   // arithmetic of the narrow kernel costs more than the rows save (measured: tools/k1g_ab.sh).  TZ_GS_KROWS=1: appended rows only.
-  g->rows_mf = (m == 1 && !getenv("TZ_GS_KROWS")) ? n : p;
+  g->rows_mf = (m == 1 && !tz_dev_getenv("TZ_GS_KROWS")) ? n : p;
   if (g->mfma && !chunks.empty()) {
     std::vector<GsChunkM> cm;
     std::vector<double> ext((size_t)p * (p + 1));
@@ -611,14 +625,14 @@ static int gs_eval(tz_genstack* g, int B, const double* de0, const double* dz, d
     const int nq = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
     nsub = split ? 2 : 1;                             // two blocks per chunk when every block streams its tiles once (measured at 32 trajectories,
     if (split) {                                      // 636 chunks: 1 -> 0.0670 ms, 2 -> 0.0641 ms, 4 -> 0.120 ms: the un-overlapped prologue of short blocks)
-      const char* e = getenv("TZ_GS_NSUB");
+      const char* e = tz_dev_getenv("TZ_GS_NSUB");
       if (e) nsub = std::min(TZ_GS_MAXSUB, std::max(1, atoi(e)));
     }
     const int ntt = split ? nsub : (B + 255) / 256;
     const bool krows = g->rows_mf == p || (B > 32 && B <= 64);       // which copy of the stack: K rows appended, or formed in the kernel
     GenstackMParams qm{B, n, m, g->N, g->nchunk, ntt, nsub, krows ? g->recs_mf.p : g->recs_mfn.p, g->K.p, g->chunks_m.p, de0, dz, g->partial.p};
     const dim3 gm((unsigned)(((g->nchunk + 7) / 8) * 8 * ntt));
-    const bool narrow = split && !getenv("TZ_GS_NO_NARROW");     // wave-private pipeline (no barrier in the stream); the switch keeps the barrier form
+    const bool narrow = split && !tz_dev_getenv("TZ_GS_NO_NARROW");     // wave-private pipeline (no barrier in the stream); the switch keeps the barrier form
 #define TZ_GS_LAUNCH(RR, PP) do { \
       if (!split) hipLaunchKernelGGL((tz_genstack_mfma_kernel<RR, PP, 4, false>), gm, dim3(256), 0, st, qm); \
       else if (narrow && nq == 1) hipLaunchKernelGGL((tz_genstack_mfma_narrow_kernel<RR, PP, 1>), gm, dim3(256), 0, st, qm); \
@@ -788,7 +802,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   std::vector<int> permc((size_t)nz), permr((size_t)mi), invc((size_t)nz), invr((size_t)mi);
   std::iota(permc.begin(), permc.end(), 0); std::iota(permr.begin(), permr.end(), 0);
   const int nv = d->N * d->m;
-  if (p->tt && getenv("TZ_NO_STAIRCASE") == nullptr) {
+  if (p->tt && !(d->plan_flags & TZ_PLAN_NO_STAIRCASE) && tz_dev_getenv("TZ_NO_STAIRCASE") == nullptr) {
     std::vector<int> rowt((size_t)mi, -1), colt((size_t)nz, 1 << 30);
     for (int r = 0; r < mi; ++r) for (int c = 0; c < nv; ++c) if (d->G[(size_t)r * nz + c] != 0.0) rowt[r] = std::max(rowt[r], c / d->m);
     for (int c = 0; c < nv; ++c) colt[c] = c / d->m;
@@ -798,7 +812,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
     std::vector<int> last((size_t)mi, -1);
     for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) if (d->G[(size_t)r * nz + c] != 0.0) last[r] = std::max(last[r], invc[c]);
     std::stable_sort(permr.begin(), permr.end(), [&](int a, int b) { return last[a] < last[b]; });
-    p->permc = permc; p->permr = permr;
+    p->permc = permc; p->permr = permr; p->staircase = true;
     std::vector<int> vp((size_t)nv);
     for (int c = 0; c < nv; ++c) vp[c] = invc[c];
     TZ_HIP(p->vpos.upload(vp));
@@ -1047,8 +1061,10 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   } else {
     p->ksplit = (p->Tz <= TZ_KS_TZ);
     p->chol1 = (p->Tz <= 16);
-    if (const char* e = getenv("TZ_CHOL1")) { if (e[0] == '0') p->chol1 = false; }
-    if (const char* e = getenv("TZ_KSPLIT")) { if (e[0] == '0') p->ksplit = false; }
+    if (d->plan_flags & TZ_PLAN_GENERAL_CHOLESKY) p->chol1 = false;
+    if (d->plan_flags & TZ_PLAN_ITEM_GRAM) p->ksplit = false;
+    if (const char* e = tz_dev_getenv("TZ_CHOL1")) { if (e[0] == '0') p->chol1 = false; }
+    if (const char* e = tz_dev_getenv("TZ_KSPLIT")) { if (e[0] == '0') p->ksplit = false; }
     p->hsize = (size_t)p->nquads * TZ_QSTR;
     // nz <= 64: the 128-register variant, h and G x of the rows parked in LDS
     p->lds_bytes = tz_ipm_lds_doubles(p->hsize, 0, Tz, nzp, mip, p->nklist, p->ntheta, p->ksplit ? 1 : 0, p->ntube, p->nell, 1) * sizeof(double);
@@ -1059,10 +1075,11 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   }
   if (!p->ipm_fn) TZ_FAIL(TZ_ERR_UNSUPPORTED, "this development build (TZ_ONLY_SMALL) carries only the mi <= 256, nz <= 64 kernel");
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
-  if (const char* e = getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
+  if (const char* e = tz_dev_getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
   if (p->prof && !TZ_PROFILE) TZ_FAIL(TZ_ERR_INVALID, "TZ_PROF=1 needs the diagnostic build of the library (libtzddpc_hip_prof.so)");
-  if (const char* e = getenv("TZ_WARM")) { p->warm_enabled = (e[0] != '0'); }
-  if (const char* e = getenv("TZ_FUSE")) { p->fuse_enabled = (e[0] != '0'); }
+  if (const char* e = tz_dev_getenv("TZ_WARM")) { p->warm_enabled = (e[0] != '0'); }
+  if (d->plan_flags & TZ_PLAN_UNFUSED) p->fuse_enabled = false;
+  if (const char* e = tz_dev_getenv("TZ_FUSE")) { p->fuse_enabled = (e[0] != '0'); }
   // the tube pass of the fused step keeps |C_K^l e0| (pmax n doubles) in the factor storage, which is free at that point: a short-horizon,
   // large-n problem whose factor is smaller than that runs the four-kernel step instead (tz_tube_kernel has its own scratch)
   if ((size_t)std::max(p->pmax, 1) * p->n > p->hsize) p->fuse_enabled = false;
@@ -1070,7 +1087,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
   // that does not parse or lies outside fails the create call instead of silently changing the solver's accuracy
   {
     auto envd = [](const char* name, double lo, bool lo_open, double hi, double& dst) -> bool {
-      const char* e = getenv(name);
+      const char* e = tz_dev_getenv(name);
       if (!e) return true;
       char* end = nullptr;
       const double v = strtod(e, &end);
@@ -1346,6 +1363,16 @@ int tz_ipm_plan_info(tz_problem* p, int64_t* mfma_gram_per_iter, int64_t* mfma_c
   if (mfma_issued_per_iter) *mfma_issued_per_iter = p->mfma_issued;
   if (lds_bytes) *lds_bytes = (int64_t)p->lds_bytes;
   if (patch_bytes) *patch_bytes = (int64_t)p->Gp.n * 8;
+  return TZ_OK;
+}
+
+int tz_problem_plan_get(tz_problem* p, int32_t* fused, int32_t* one_wave_cholesky, int32_t* superstep_gram, int32_t* staircase, int32_t* toeplitz) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  if (fused) *fused = p->fuse_enabled ? 1 : 0;
+  if (one_wave_cholesky) *one_wave_cholesky = p->chol1 ? 1 : 0;
+  if (superstep_gram) *superstep_gram = p->ksplit ? 1 : 0;
+  if (staircase) *staircase = p->staircase ? 1 : 0;
+  if (toeplitz) *toeplitz = p->toeplitz ? 1 : 0;
   return TZ_OK;
 }
 

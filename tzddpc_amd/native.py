@@ -11,7 +11,7 @@ from typing import Optional
 
 import numpy as np
 
-TZ_ABI_VERSION = 3
+TZ_ABI_VERSION = 4
 TZ_MEM_HOST, TZ_MEM_DEVICE = 0, 1
 TZ_SOLVED, TZ_MAX_ITER, TZ_NUMERICAL, TZ_INFEASIBLE = 0, 1, 2, 3
 
@@ -45,7 +45,12 @@ class ProblemDesc(C.Structure):
         ("max_iter", C.c_int32), ("tol", C.c_double), ("reg", C.c_double), ("step_frac", C.c_double),
         ("shift_var", _ip), ("shift_row", _ip), ("shift_xscale", _dp), ("shift_lscale", _dp),
         ("rec_c0", _dp), ("rec_x0", _dp), ("rec_y", _dp),
+        ("plan_flags", C.c_int32),
     ]
+
+
+# tz_problem_desc.plan_flags (include/tzddpc.h): force the general-size code paths (parity tests hold the paths against each other)
+TZ_PLAN_UNFUSED, TZ_PLAN_GENERAL_CHOLESKY, TZ_PLAN_ITEM_GRAM, TZ_PLAN_NO_STAIRCASE, TZ_PLAN_ELL_PRODUCTS = 1, 2, 4, 8, 16
 
 
 class GenstackDesc(C.Structure):
@@ -128,7 +133,7 @@ def lib():
     return L
 
 
-EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy",
+EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy", "tz_problem_plan_get",
                     "tz_problem_set_stream", "tz_problem_sync", "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run",
                     "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch",
                     "tz_problem_set_warm_shift", "tz_problem_set_stopping", "tz_problem_set_warm_quiet", "tz_problem_set_warm_push", "tz_problem_reset_warm", "tz_identify_batch", "tz_specrad_batch", "tz_adversary_batch",
@@ -235,7 +240,7 @@ class Problem:
     def __init__(self, device: int, *, n, m, N, P, G, q0, Qt, h0, Ht, par0, Part, par_lo, par_hi, cost_scale, r0, r1, R2,
                  Dz, Phi, Gam, nc_rows, row_of, act_scale, CK, DK, K, pmax, absCKpow, absKCKpow, power,
                  max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999,
-                 shift_var=None, shift_row=None, shift_xscale=None, shift_lscale=None, rec_c0=None, rec_x0=None, rec_y=None):
+                 shift_var=None, shift_row=None, shift_xscale=None, shift_lscale=None, rec_c0=None, rec_x0=None, rec_y=None, plan_flags=0):
         L = lib()
         keep = []
         d = ProblemDesc()
@@ -257,6 +262,7 @@ class Problem:
         d.nc_rows = int(nc_rows); d.row_of = _ptr(ro, _ip)
         d.pmax = int(pmax); d.power = _ptr(pw, _ip)
         d.max_iter = int(max_iter); d.tol = float(tol); d.reg = float(reg); d.step_frac = float(step_frac)
+        d.plan_flags = int(plan_flags)
         if shift_var is not None:
             sv, sr, xs, ls = _i32(shift_var), _i32(shift_row), _f64(shift_xscale), _f64(shift_lscale)
             keep += [sv, sr, xs, ls]
@@ -378,8 +384,11 @@ class Problem:
     def plan_info(self):
         a, b, i, c, d = (C.c_int64(0) for _ in range(5))
         check(lib().tz_ipm_plan_info(self._h, C.byref(a), C.byref(b), C.byref(i), C.byref(c), C.byref(d)), "tz_ipm_plan_info")
+        f = [C.c_int32(0) for _ in range(5)]
+        check(lib().tz_problem_plan_get(self._h, *[C.byref(v) for v in f]), "tz_problem_plan_get")
         return dict(mfma_gram_per_iter=a.value, mfma_chol_per_iter=b.value, mfma_issued_per_iter=i.value,
-                    lds_bytes=c.value, patch_bytes=d.value)
+                    lds_bytes=c.value, patch_bytes=d.value, fused=bool(f[0].value), chol1=bool(f[1].value), ksplit=bool(f[2].value),
+                    staircase=bool(f[3].value), toeplitz=bool(f[4].value))
 
     def last_iterations(self, B: int) -> np.ndarray:
         """Interior-point iterations of each trajectory in the last launch (diagnostic)."""

@@ -341,7 +341,8 @@ class TZDDPC(object):
         sr = np.array([pos.get((int(sr2[row_red[k]]), int(side[k])), k) for k in range(len(row_red))], dtype=np.int32)
         shift = dict(shift_var=sv.astype(np.int32), shift_row=sr, shift_xscale=D[sv] / D, shift_lscale=E[sr] / E)
         opts = dict(max_iter=int(solver_kwargs.pop("max_iter", 40)), tol=float(solver_kwargs.pop("tol", 1e-10)),
-                    reg=float(solver_kwargs.pop("reg", 1e-12)), step_frac=float(solver_kwargs.pop("step_frac", 0.99999)))
+                    reg=float(solver_kwargs.pop("reg", 1e-12)), step_frac=float(solver_kwargs.pop("step_frac", 0.99999)),
+                    plan_flags=int(solver_kwargs.pop("plan_flags", 0)))
         nat = native.Problem(
             self.device, n=n, m=m, N=int(horizon),
             P=c * D[:, None] * qp.P * D[None, :], G=E[:, None] * G * D[None, :],
@@ -510,7 +511,7 @@ class TZDDPC(object):
         from .builder import build_simplified2_qp
         ze_sum = str(solver_kwargs.pop("ze_sum", "radius"))
         zs = [(np.asarray(Z.center, float), np.asarray(Z.generators, float)) for Z in Zsigma]
-        consumed = tuple((k, solver_kwargs.get(k)) for k in ("max_iter", "tol", "reg", "step_frac"))      # read by _native_from_qp below
+        consumed = tuple((k, solver_kwargs.get(k)) for k in ("max_iter", "tol", "reg", "step_frac", "plan_flags"))      # read by _native_from_qp below
         key = (int(horizon), build_loss, build_constraints, ze_sum, consumed, tuple(c.tobytes() + g.tobytes() for c, g in zs),
                np.asarray(self.theta.K).tobytes(), np.asarray(self.theta.deltaA).tobytes(), np.asarray(self.theta.deltaB).tobytes())
         cur = getattr(self, "_s2", None)
