@@ -315,9 +315,12 @@ def test_fused_step_equals_four_kernel_step(built):
         x0 = np.tile(zon.X0.center, (Bn, 1))
         a = fused.simulate_batch(x0, noise, A, B); b = split.simulate_batch(x0, noise, A, B)
         assert (a["status"] == 0).all() and (b["status"] == 0).all()
-        np.testing.assert_allclose(a["x"], b["x"], rtol=0, atol=1e-11)
-        np.testing.assert_allclose(a["u"], b["u"], rtol=0, atol=1e-11)
-        np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-11, atol=1e-11)
+        # same interior point on both sides; the fused step forms xbar[1] = Phi_1 xbar + Gam_1[:, :m] v[0] on one wave (round 4), the
+        # finish kernel sums over all N m inputs: last-bit differences in the nominal state, carried through ten solves (1e-16 times the
+        # sensitivity of the solution to its parameters, 5e-11 measured)
+        np.testing.assert_allclose(a["x"], b["x"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(a["u"], b["u"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-9, atol=1e-9)
 
 
 def test_single_wave_factor_path_equals_four_wave_path(built):

@@ -21,11 +21,42 @@ struct IpmItem { int I0, q0, nq, kptr, klen; };
 // G in balanced "lane-ELL" form for the matrix-vector products (built by the host, tz_problem_create): the non-zeros of every
 // output (a row of G for G x, a column for G'v) are dealt to as many consecutive virtual lanes as it takes to give every lane
 // at most L entries; entry e of virtual lane v is at [(pass * L + e) * NL + lane] with v = pass * NL + lane (NL = 256 for G x,
-// 192 for G'v: waves 1-3, wave 0 does something else meanwhile).  Every lane walks L (value, index) pairs -- coalesced,
-// no zeros fetched, equal work per lane -- and leaves one partial sum in LDS; the owner of an output adds its lanes' partial
-// sums in a fixed order (seg[o] = first lane | lanes << 16).  G is fetched once per product at ~10 B per non-zero instead of
-// 8 B per entry of the dense matrix (and of the 26 idle lanes of a 38-wide row).
-struct TzEll { int L, VL; const double* val; const unsigned short* idx; const int* seg; };
+// 192 for G'v: waves 1-3, wave 0 does something else meanwhile).  Every lane walks L entries -- coalesced, no zeros fetched,
+// equal work per lane -- and leaves one partial sum in LDS; the owner of an output adds its lanes' partial sums in a fixed
+// order (seg[o] = first lane | lanes << 16).  An entry is ONE 16-byte record (value, byte offset of the input entry, pad): one
+// vector-memory instruction and one address add per non-zero (the kernel is issue-bound, not byte-bound: 10-byte (value, 16-bit
+// index) pairs in two arrays cost two loads and a shift-add; a 4-byte value dictionary cost three LDS gathers and was slower still).
+struct TzEll { int L, VL; const TzEllEnt* ent; const int* seg; };      // TzEllEnt, tz_d2, tz_ell_off: tz_kernels.hip.h
+// one virtual lane's walk over its L records, NL lanes apart.  base: wave-uniform address of record 0 of lane 0 of the pass (scalar
+// registers, advanced by scalar adds); lo: this lane's byte offset (one 32-bit vector register): no vector address arithmetic per load
+typedef __attribute__((address_space(1))) const char* tz_gptr;
+typedef __attribute__((address_space(1))) const tz_d2* tz_gd2ptr;
+__device__ inline double tz_ell_walk(const char* base_, unsigned lo, int L, unsigned stride, const double* in) {
+  double a0 = 0.0, a1 = 0.0;
+  const char* b = reinterpret_cast<const char*>(in);
+  tz_gptr base = (tz_gptr)base_;
+  int e = 0;
+  for (; e + 3 < L; e += 4) {
+    // the four record addresses as scalar base + 32-bit lane offset (the bases pinned in scalar registers: the compiler otherwise folds
+    // base + lane offset into ONE 64-bit vector address and derives the other three from it with vector adds)
+    tz_gptr q0 = base, q1 = base + stride, q2 = base + 2 * (size_t)stride, q3 = base + 3 * (size_t)stride;
+    asm volatile("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));
+    const tz_d2 r0 = *(tz_gd2ptr)(q0 + lo), r1 = *(tz_gd2ptr)(q1 + lo), r2 = *(tz_gd2ptr)(q2 + lo), r3 = *(tz_gd2ptr)(q3 + lo);
+    base += 4 * (size_t)stride;
+    a0 += r0.x * *reinterpret_cast<const double*>(b + tz_ell_off(r0.y));
+    a1 += r1.x * *reinterpret_cast<const double*>(b + tz_ell_off(r1.y));
+    a0 += r2.x * *reinterpret_cast<const double*>(b + tz_ell_off(r2.y));
+    a1 += r3.x * *reinterpret_cast<const double*>(b + tz_ell_off(r3.y));
+  }
+  for (; e < L; ++e) {
+    tz_gptr q0 = base;
+    asm volatile("" : "+s"(q0));
+    const tz_d2 r = *(tz_gd2ptr)(q0 + lo);
+    base += stride;
+    a0 += r.x * *reinterpret_cast<const double*>(b + tz_ell_off(r.y));
+  }
+  return a0 + a1;
+}
 
 struct IpmParams {
   int B, nz, mi, nzp, mip, Tz, Kc, nquads, nklist, nP;   // nP: rows of P beyond which P is zero
@@ -101,7 +132,7 @@ __device__ inline int tz_tid() {
 // another 3.8 % (A/B on one box: 2 / 1 beats 1 / 0, 1 / 1 and 2 / 2).
 #define TZ_PRIO_ELEM 1
 #define TZ_PRIO_GLUE 2
-enum { RED_SUM = 0, RED_MAX = 1, RED_MIN = 2 };
+enum { RED_SUM = 0, RED_MAX = 1, RED_MIN = 2, RED_MAXU = 3 };
 
 // 64-bit DPP move (two 32-bit halves).  mov_dpp with bound_ctrl instead of update_dpp(0, ...): no `old` operand to initialise -- the
 // compiler materialised the zero with two more moves per call (quad permutes and row rotations read valid lanes only: same values)
@@ -121,7 +152,7 @@ __device__ inline double tz_readlane(double v, int lane) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 template <int OP>
-__device__ inline double tz_op(double a, double b) { return (OP == RED_SUM) ? a + b : (OP == RED_MAX ? fmax(a, b) : fmin(a, b)); }
+__device__ inline double tz_op(double a, double b) { return (OP == RED_SUM) ? a + b : ((OP == RED_MAX || OP == RED_MAXU) ? fmax(a, b) : fmin(a, b)); }
 
 // Reduction over the 64 lanes of a wave, result in every lane.  Cross-lane moves by DPP (quad permutes, row rotations) and four
 // v_readlane for the rows of 16 -- no ds_bpermute round trips through the LDS crossbar.  Fixed combination order.
@@ -172,22 +203,60 @@ __device__ inline void tz_wave_reduce3(double& a, double& b, double& c) {
   a = tz_readlane(a, 63); if (NV > 1) b = tz_readlane(b, 63); if (NV > 2) c = tz_readlane(c, 63);
 }
 
+// RED_MAXU: maximum of NON-NEGATIVE values, rounded UP to the next multiple of 2^-20 relative (or left exact when it is inf / NaN).
+// The order of non-negative doubles is the order of their bit patterns, so the maximum of the HIGH 32-bit words is found with one
+// v_max_u32 per stage, the cross-lane move fused into it as its DPP operand -- 7 vector instructions per value instead of the 19 of
+// the f64 tree (every f64 stage is two 32-bit DPP moves plus the operation: f64 instructions take no DPP operand).  Every use is a
+// quantity that only enters a threshold test or the length of a step (residual norms, step-to-boundary ratios, the violation that
+// sizes the warm-start push, the scales of the stopping test): overestimating it by <= 1e-6 relative makes the test a hair stricter
+// and the step a hair shorter.  Deterministic; NaN and inf survive (their patterns are the largest).
+template <int CTRL, int ROWMASK>
+__device__ inline unsigned tz_dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, ROWMASK == 0xf); }
+__device__ inline unsigned tz_hi(double v) { return (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32); }
+__device__ inline unsigned tz_wave_maxu(unsigned u) {
+  u = max(u, tz_dpp_u32<0xB1, 0xf>(u)); u = max(u, tz_dpp_u32<0x4E, 0xf>(u));
+  u = max(u, tz_dpp_u32<0x124, 0xf>(u)); u = max(u, tz_dpp_u32<0x128, 0xf>(u));
+  u = max(u, tz_dpp_u32<0x142, 0xA>(u)); u = max(u, tz_dpp_u32<0x143, 0xC>(u));
+  return (unsigned)__builtin_amdgcn_readlane((int)u, 63);
+}
+__device__ inline double tz_from_hi_up(unsigned u) {
+  u += (u < 0x7FEFFFFFu) ? 1u : 0u;
+  return __builtin_bit_cast(double, (unsigned long long)u << 32);
+}
+
+// the four waves' results of one value (slots q[0..3]); a RED_MAXU value is a high word parked in the low half of its slot
+template <int OP>
+__device__ inline double tz_fold4(const double* q) {
+  if (OP == RED_MAXU) {
+    const unsigned* u = reinterpret_cast<const unsigned*>(q);
+    return tz_from_hi_up(max(max(u[0], u[2]), max(u[4], u[6])));
+  }
+  return tz_op<OP>(tz_op<OP>(tz_op<OP>(q[0], q[1]), q[2]), q[3]);
+}
+
 template <int OP0, int OP1, int OP2, int NV = 3>
 __device__ inline void tz_block_reduce3(double& a, double& b, double& c, double* red, int& par) {
-  tz_wave_reduce3<OP0, OP1, OP2, NV>(a, b, c);
+  constexpr bool U0 = OP0 == RED_MAXU, U1 = NV > 1 && OP1 == RED_MAXU, U2 = NV > 2 && OP2 == RED_MAXU;
+  // the f64 values go through the stages side by side; the RED_MAXU ones as high words
+  unsigned ua = 0, ub = 0, uc = 0;
+  if (U0) ua = tz_wave_maxu(tz_hi(a));
+  if (U1) ub = tz_wave_maxu(tz_hi(b));
+  if (U2) uc = tz_wave_maxu(tz_hi(c));
+  constexpr int NF = (U0 ? 0 : 1) + ((NV > 1 && !U1) ? 1 : 0) + ((NV > 2 && !U2) ? 1 : 0);
+  if (NF == 3) tz_wave_reduce3<OP0, OP1, OP2, 3>(a, b, c);
+  else if (NF == 2) { if (U0) tz_wave_reduce3<OP1, OP2, OP2, 2>(b, c, a); else if (U1) tz_wave_reduce3<OP0, OP2, OP2, 2>(a, c, b); else tz_wave_reduce3<OP0, OP1, OP1, 2>(a, b, c); }
+  else if (NF == 1) { if (!U0) tz_wave_reduce3<OP0, OP0, OP0, 1>(a, b, c); else if (NV > 1 && !U1) tz_wave_reduce3<OP1, OP1, OP1, 1>(b, a, c); else tz_wave_reduce3<OP2, OP2, OP2, 1>(c, a, b); }
   const int tt = tz_tid();
   int lane = tt & 63, w = tt >> 6;
   double* rb_ = red + (par ? 16 : 0);
   par ^= 1;
-  if (lane == 0) { rb_[w] = a; if (NV > 1) rb_[4 + w] = b; if (NV > 2) rb_[8 + w] = c; }
-  __syncthreads();
-  double ra = rb_[0], rb = (NV > 1) ? rb_[4] : 0.0, rc = (NV > 2) ? rb_[8] : 0.0;
-#pragma unroll
-  for (int i = 1; i < TZ_NWAVES; ++i) {
-    ra = tz_op<OP0>(ra, rb_[i]);
-    if (NV > 1) rb = tz_op<OP1>(rb, rb_[4 + i]);
-    if (NV > 2) rc = tz_op<OP2>(rc, rb_[8 + i]);
+  if (lane == 0) {
+    rb_[w] = U0 ? __builtin_bit_cast(double, (unsigned long long)ua) : a;
+    if (NV > 1) rb_[4 + w] = U1 ? __builtin_bit_cast(double, (unsigned long long)ub) : b;
+    if (NV > 2) rb_[8 + w] = U2 ? __builtin_bit_cast(double, (unsigned long long)uc) : c;
   }
+  __syncthreads();
+  const double ra = tz_fold4<OP0>(rb_), rb = (NV > 1) ? tz_fold4<OP1>(rb_ + 4) : 0.0, rc = (NV > 2) ? tz_fold4<OP2>(rb_ + 8) : 0.0;
   a = ra; if (NV > 1) b = rb; if (NV > 2) c = rc;
 }
 
@@ -233,25 +302,16 @@ __device__ inline double tz_gemvT_get3(const double* part, int nzp, int c) {
   return (part[c] + part[nzp + c]) + part[2 * nzp + c];
 }
 
-// out[k] = (G in)_r for the rows r = t + 256 k this thread owns; `in` (nz entries) and pl (eg.VL doubles) in LDS.
-template <int MAXR>
-__device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double* pl, const int (&rseg)[MAXR], double (&out)[MAXR]) {
+// out[k] = (G in)_r for the rows r = t + 256 k this thread owns; `in` (nz entries) and pl (eg.VL doubles) in LDS.  Two halves: every
+// thread walks its virtual lanes (tz_ell_gemv_walk; pl must not be in use by the owners of an earlier product), and after a workgroup
+// barrier the owner of a row adds its lanes' partial sums (tz_ell_gemv_sum).
+__device__ inline void tz_ell_gemv_walk(const IpmParams& p, const double* in, double* pl) {
   const int t = tz_tid(), L = p.eg.L;
-  __syncthreads();                                   // pl may still be read by the owners of the previous product
-  for (int v0 = 0; v0 < p.eg.VL; v0 += TZ_THREADS) {
-    const double* val = p.eg.val + (size_t)v0 * L + t;
-    const unsigned short* idx = p.eg.idx + (size_t)v0 * L + t;
-    double a0 = 0.0, a1 = 0.0;
-    int e = 0;
-    for (; e + 3 < L; e += 4) {
-      const double x0 = val[(size_t)e * TZ_THREADS], x1 = val[(size_t)(e + 1) * TZ_THREADS], x2 = val[(size_t)(e + 2) * TZ_THREADS], x3 = val[(size_t)(e + 3) * TZ_THREADS];
-      const int i0 = idx[(size_t)e * TZ_THREADS], i1 = idx[(size_t)(e + 1) * TZ_THREADS], i2 = idx[(size_t)(e + 2) * TZ_THREADS], i3 = idx[(size_t)(e + 3) * TZ_THREADS];
-      a0 += x0 * in[i0]; a1 += x1 * in[i1]; a0 += x2 * in[i2]; a1 += x3 * in[i3];
-    }
-    for (; e < L; ++e) a0 += val[(size_t)e * TZ_THREADS] * in[idx[(size_t)e * TZ_THREADS]];
-    pl[v0 + t] = a0 + a1;
-  }
-  __syncthreads();
+  for (int v0 = 0; v0 < p.eg.VL; v0 += TZ_THREADS)
+    pl[v0 + t] = tz_ell_walk(reinterpret_cast<const char*>(p.eg.ent + (size_t)v0 * L), (unsigned)t * 16u, L, TZ_THREADS * 16u, in);
+}
+template <int MAXR>
+__device__ inline void tz_ell_gemv_sum(const double* pl, const int (&rseg)[MAXR], double (&out)[MAXR]) {
 #pragma unroll
   for (int k = 0; k < MAXR; ++k) {
     double a = 0.0;
@@ -262,25 +322,21 @@ __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double*
     out[k] = a;
   }
 }
+template <int MAXR>
+__device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double* pl, const int (&rseg)[MAXR], double (&out)[MAXR]) {
+  __syncthreads();                                   // pl may still be read by the owners of the previous product
+  tz_ell_gemv_walk(p, in, pl);
+  __syncthreads();
+  tz_ell_gemv_sum<MAXR>(pl, rseg, out);
+}
 
 // Partial sums of G'in by the 192 threads of waves 1-3 (the caller keeps wave 0 out); `in` (mi entries), pl (et.VL doubles) in
 // LDS.  After the next workgroup barrier tz_ell_colsum(pl, cseg) is column c's value for the thread holding cseg = et.seg[c].
 __device__ inline void tz_ell_gemvT_part(const IpmParams& p, const double* in, double* pl) {
   constexpr int NL = TZ_THREADS - 64;
   const int l = tz_tid() - 64, L = p.et.L;
-  for (int v0 = 0; v0 < p.et.VL; v0 += NL) {
-    const double* val = p.et.val + (size_t)v0 * L + l;
-    const unsigned short* idx = p.et.idx + (size_t)v0 * L + l;
-    double a0 = 0.0, a1 = 0.0;
-    int e = 0;
-    for (; e + 3 < L; e += 4) {
-      const double x0 = val[(size_t)e * NL], x1 = val[(size_t)(e + 1) * NL], x2 = val[(size_t)(e + 2) * NL], x3 = val[(size_t)(e + 3) * NL];
-      const int i0 = idx[(size_t)e * NL], i1 = idx[(size_t)(e + 1) * NL], i2 = idx[(size_t)(e + 2) * NL], i3 = idx[(size_t)(e + 3) * NL];
-      a0 += x0 * in[i0]; a1 += x1 * in[i1]; a0 += x2 * in[i2]; a1 += x3 * in[i3];
-    }
-    for (; e < L; ++e) a0 += val[(size_t)e * NL] * in[idx[(size_t)e * NL]];
-    pl[v0 + l] = a0 + a1;
-  }
+  for (int v0 = 0; v0 < p.et.VL; v0 += NL)
+    pl[v0 + l] = tz_ell_walk(reinterpret_cast<const char*>(p.et.ent + (size_t)v0 * L), (unsigned)l * 16u, L, NL * 16u, in);
 }
 __device__ inline double tz_ell_colsum(const double* pl, int cseg) {
   double a = 0.0;
@@ -881,6 +937,8 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   const int b = blockIdx.x;
   int t = threadIdx.x;                     // re-laundered at phase boundaries (TZ_FRESH_T, see tz_tid)
 #define TZ_FRESH_T() asm volatile("" : "+v"(t))
+  // columns: nz <= nzp <= 256 = TZ_THREADS (limit of tz_problem_create), so "every column" is one predicated statement, not a loop
+#define TZ_COLS(c, lim) if (const int c = t; c < (lim))
   const bool wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
   const bool wave1 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1;
   const int nz = p.nz, mi = p.mi, nzp = p.nzp, mip = p.mip;
@@ -888,7 +946,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   const bool fused = F0.on != 0;          // closed-loop step in one launch: tube + parameter maps before, recovery + plant after
   if (!fused && p.prestatus[b] != 0) {
     if (t == 0) { p.status[b] = 3; p.iters[b] = 0; if (p.status_copy) p.status_copy[b] = 3; }
-    for (int c = t; c < nz; c += TZ_THREADS) p.x[(size_t)b * nz + c] = 0.0;
+    TZ_COLS(c, nz) p.x[(size_t)b * nz + c] = 0.0;
     for (int r = t; r < mi; r += TZ_THREADS) { p.s[(size_t)b * mi + r] = 1.0; p.lam[(size_t)b * mi + r] = 0.0; }
     return;
   }
@@ -971,8 +1029,9 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   }
 #pragma unroll
   for (int k = 0; k < MAXR; ++k) { s_[k] = 1.0; l_[k] = 0.0; h_[k] = 0.0; gx_[k] = 0.0; }
-  for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
+  TZ_COLS(c, nzp) xv[c] = 0.0;
   for (int c = t; c < p.Tz * 16; c += TZ_THREADS) dinv[c] = 0.0;
+  for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = 0.0;          // rows written per use; the pad behind row mi is read by the Gram and stays zero
   __syncthreads();
 
   const int nsteps = fused ? F0.nsteps : 1;
@@ -1000,19 +1059,45 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   // has its own) -- fetched now, parked in LDS at the end of the prologue
   double wpre = 0.0;
   if (fused && t < F.fin.n) wpre = F.plant.w[(size_t)b * F.plant.w_stride + (size_t)step * F.w_step + t];
-  for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;       // w = 1 for the cold start point
+  // warm-start policy of this step (uniform): the previous solution, optionally moved one step along the horizon (v_k <- v_{k+1} ...:
+  // better in a transient, a matter of the problem otherwise -- tz_problem_set_warm_shift)
+  bool shifted = false;
+  if (src != 0) {
+    const int prev_it = (step == 0) ? pk.iters[b] : it;
+    const bool quiet_run = was_shifted != 0 && prev_it <= 1;
+    const int nquiet = quiet_run ? was_shifted : 0;                       // was_shifted - 1 quiet steps so far, this one included: was_shifted
+    shifted = pk.shift_policy == 1 || (pk.shift_policy >= 2 && (prev_it >= pk.shift_policy || (quiet_run && (pk.shift_quiet == 0 || nquiet <= pk.shift_quiet))));
+    was_shifted = shifted ? 1 + nquiet : 0;
+  }
+  // A step that starts from the previous step of the same launch (src == 2: x in LDS, lambda in registers) runs the warm start INSIDE the
+  // barrier intervals of the prologue: the two halves of the horizon shift beside the two stages of the tube pass, the walk of G x
+  // beside the parameter maps (neither depends on theta) -- four workgroup barriers from the plant update of one step to the
+  // warm-start reduction of the next instead of seven.  G x of the starting point: inside a launch gx_ still holds it (it followed x
+  // through the iterations of the previous step); it is formed afresh every eighth step (rounding) and whenever the point was shifted.
+  const bool inlaunch = fused && src == 2;
+  const bool walk_early = inlaunch && (shifted || (step & 7) == 0);
   if (fused) {
     if (t == 0) { flag[0] = 0; flag[1] = 0; }
-    {                                                                                  // the factor storage is free until the first Gram
-      const int n = F.fin.n, m = F.fin.m, nv = F.fin.N * m;
-      const double* Tt = tbl + (F.tube.pmax + 1) * n * n;
-      const int* pwl = (const int*)(Tt + (F.tube.pmax > 0 ? F.tube.pmax : 1) * (n + m) * n + 3 * n * n + 2 * n * m + n + n * nv + nv);
-      if (n == 2 && m == 1) tz_tube_block<2, 1>(F.tube, tbl, Tt, pwl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS);
-      else tz_tube_block(F.tube, tbl, Tt, pwl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS);
+    const int n = F.fin.n, m = F.fin.m, nv = F.fin.N * m;
+    const double* Tt = tbl + (F.tube.pmax + 1) * n * n;
+    const int* pwl = (const int*)(Tt + (F.tube.pmax > 0 ? F.tube.pmax : 1) * (n + m) * n + 3 * n * n + 2 * n * m + n + n * nv + nv);
+    // the factor storage is free until the first Gram: |C_K^l e0| goes there
+    if (n == 2 && m == 1) tz_tube_stage1<2, 1>(F.tube, tbl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS);
+    else tz_tube_stage1(F.tube, tbl, stl + n, stl + 2 * n, Hq, thl, t, TZ_THREADS);
+    if (inlaunch && shifted) {
+      TZ_COLS(c, nz) tmpz[c] = xv[pk.sx[c]] * pk.sxs[c];
+      TZ_ROWS(k, r) vin[r] = l_[k];
+    }
+    __syncthreads();
+    if (n == 2 && m == 1) tz_tube_stage2<2, 1>(F.tube, tbl, Tt, pwl, stl + 2 * n, Hq, thl, t, TZ_THREADS);
+    else tz_tube_stage2(F.tube, tbl, Tt, pwl, stl + 2 * n, Hq, thl, t, TZ_THREADS);
+    if (inlaunch && shifted) {
+      TZ_COLS(c, nz) xv[c] = tmpz[c];
+      TZ_ROWS(k, r) l_[k] = vin[pk.sr[r]] * pk.sls[r];
     }
     __syncthreads();
     TZ_STAMP(PH_TUBE);
-    for (int c = t; c < nzp; c += TZ_THREADS) { qv[c] = (c < nz) ? csr_row(F.qmap, c, thl) : 0.0; if (src != 2) xv[c] = 0.0; }
+    TZ_COLS(c, nzp) { qv[c] = (c < nz) ? csr_row(F.qmap, c, thl) : 0.0; if (src != 2) xv[c] = 0.0; }
     TZ_STAMP(PH_MAPS_Q);
     int bad = 0;
     for (int r = t; r < F.npar; r += TZ_THREADS) {
@@ -1021,15 +1106,16 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     }
     if (bad) flag[1] = 1;
     TZ_ROWS(k, r) TZ_SET_H(k, r, csr_row(F.hmap, r, thl));
+    if (walk_early) tz_ell_gemv_walk(p, xv, pl);         // (pl: last read before the barriers above)
   } else {
-    for (int c = t; c < nzp; c += TZ_THREADS) qv[c] = (c < nz) ? pk.q[(size_t)b * nz + c] : 0.0;
+    TZ_COLS(c, nzp) qv[c] = (c < nz) ? pk.q[(size_t)b * nz + c] : 0.0;
     TZ_ROWS(k, r) TZ_SET_H(k, r, pk.h[(size_t)b * mi + r]);
     if (t == 0) *flag = 0;
   }
   if (src != 2) { TZ_ROWS(k, r) l_[k] = 1.0; }
   if (fused && t < F.fin.n) stl[3 * TZ_NMAX + t] = wpre;
   __syncthreads();
-  if (fused && flag[1] != 0) { skip = true; TZ_ROWS(k, r) { s_[k] = 1.0; l_[k] = 0.0; } for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0; }
+  if (fused && flag[1] != 0) { skip = true; TZ_ROWS(k, r) { s_[k] = 1.0; l_[k] = 0.0; } TZ_COLS(c, nzp) xv[c] = 0.0; }
   TZ_STAMP(PH_PROLOGUE);
 
   // exact dual residual rd = P x + q + G'lam into rdv (used at the start and to confirm convergence)
@@ -1062,7 +1148,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
       if (t < nzp) rdv[t] = (t < nz) ? (tz_ell_colsum(pl, cseg) + qv[t]) + part[t] : 0.0;
       __syncthreads();
       double e2 = 0, e3 = 0;
-      for (int c = t; c < nz; c += TZ_THREADS) e1 = fmax(e1, fabs(rdv[c]));
+      TZ_COLS(c, nz) e1 = fmax(e1, fabs(rdv[c]));
       tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX, 1>(e1, e2, e3, red, rpar);
     }
     TZ_STAMP(PH_RD_C);
@@ -1081,36 +1167,22 @@ retry_solve:
   if (warm) {
     // ---- warm start: previous (x, lambda) of this trajectory, slacks re-derived for the new h and pushed into the cone
     // by at least the amount the old point violates the new rows; a point that is too far outside starts cold instead
-    // the previous solution, optionally moved one step along the horizon (v_k <- v_{k+1} ...: better in a transient, a matter of
-    // the problem otherwise -- tz_problem_set_warm_shift)
-    const int prev_it = (step == 0) ? pk.iters[b] : it;
-    const bool quiet_run = was_shifted != 0 && prev_it <= 1;
-    const int nquiet = quiet_run ? was_shifted : 0;                       // was_shifted - 1 quiet steps so far, this one included: was_shifted
-    const bool shifted = pk.shift_policy == 1 || (pk.shift_policy >= 2 && (prev_it >= pk.shift_policy || (quiet_run && (pk.shift_quiet == 0 || nquiet <= pk.shift_quiet))));
-    was_shifted = shifted ? 1 + nquiet : 0;
     if (src == 1) {
       if (shifted) {
-        for (int c = t; c < nz; c += TZ_THREADS) xv[c] = pk.x[(size_t)b * nz + pk.sx[c]] * pk.sxs[c];
+        TZ_COLS(c, nz) xv[c] = pk.x[(size_t)b * nz + pk.sx[c]] * pk.sxs[c];
         TZ_ROWS(k, r) l_[k] = pk.lam[(size_t)b * mi + pk.sr[r]] * pk.sls[r];
       } else {
-        for (int c = t; c < nz; c += TZ_THREADS) xv[c] = pk.x[(size_t)b * nz + c];
+        TZ_COLS(c, nz) xv[c] = pk.x[(size_t)b * nz + c];
         TZ_ROWS(k, r) l_[k] = pk.lam[(size_t)b * mi + r];
       }
-    } else if (shifted) {                                   // src == 2: x in LDS, lambda in registers of the row owners
-      for (int c = t; c < nz; c += TZ_THREADS) tmpz[c] = xv[pk.sx[c]] * pk.sxs[c];
-      TZ_ROWS(k, r) vin[r] = l_[k];
-      __syncthreads();
-      for (int c = t; c < nz; c += TZ_THREADS) xv[c] = tmpz[c];
-      TZ_ROWS(k, r) l_[k] = vin[pk.sr[r]] * pk.sls[r];
     }
-    // G x of the starting point: inside a launch gx_ still holds it (it followed x through the iterations of the previous
-    // step); it is formed afresh every eighth step so that rounding does not accumulate along a trajectory
-    if (src != 2 || (step & 7) == 0 || retried || shifted) { tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
+    if (walk_early && !retried) { tz_ell_gemv_sum<MAXR>(pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }     // walked in the prologue
+    else if (src != 2 || retried) { tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
     TZ_STAMP(PH_WARM_A);
     double viol = 0.0;
     TZ_ROWS(k, r) { const double hv = TZ_H(k, r); viol = fmax(viol, TZ_GX(k, r) - hv); sch = fmax(sch, fabs(hv)); }
-    for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
-    tz_block_reduce3<RED_MAX, RED_MAX, RED_MAX>(viol, scq, sch, red, rpar);      // also the scales of the stopping test
+    TZ_COLS(c, nz) scq = fmax(scq, fabs(qv[c]));
+    tz_block_reduce3<RED_MAXU, RED_MAXU, RED_MAXU>(viol, scq, sch, red, rpar);      // also the scales of the stopping test
     TZ_STAMP(PH_WARM_B);
     const double sig = fmin(fmax(pk.warm_floor, pk.warm_gain * viol), pk.warm_cap);
     const double sig2 = sig * sig;
@@ -1123,6 +1195,8 @@ retry_solve:
   if (!warm) {
     was_shifted = 0;
     // ---- cold start: (P + G'G + reg) x = -q + G'h, then shift the slacks into the cone
+    TZ_ROWS(k, r) vin[r] = 1.0;                          // w = 1 for the cold start point (the entries behind row mi stay zero for the whole launch)
+    __syncthreads();
     if constexpr (TT) tz_gram_tt<TZ_TT_GU(MINW), TZ_TT_NST>(p, Hq, vin); else tz_gram(p, Hq, Pq, vin, kl);
     __syncthreads();
     TZ_ROWS(k, r) vin[r] = TZ_H(k, r);
@@ -1144,7 +1218,7 @@ retry_solve:
     double rmin = 1e300;
     scq = 0.0; sch = 0.0;
     TZ_ROWS(k, r) { const double hv = TZ_H(k, r); rmin = fmin(rmin, hv - TZ_GX(k, r)); sch = fmax(sch, fabs(hv)); }
-    for (int c = t; c < nz; c += TZ_THREADS) scq = fmax(scq, fabs(qv[c]));
+    TZ_COLS(c, nz) scq = fmax(scq, fabs(qv[c]));
     tz_block_reduce3<RED_MIN, RED_MAX, RED_MAX>(rmin, scq, sch, red, rpar);
     const double shift = (rmin <= 1e-8) ? fmax(0.0, 1.0 - rmin) : 0.0;
     TZ_ROWS(k, r) s_[k] = TZ_H(k, r) - TZ_GX(k, r) + shift;
@@ -1180,7 +1254,7 @@ retry_solve:
     double nrp = 0, sl = 0, z0 = 0;
     TZ_ROWS(k, r) { rp_[k] = TZ_GX(k, r) + s_[k] - TZ_H(k, r); nrp = fmax(nrp, fabs(rp_[k])); sl += s_[k] * l_[k]; }
     TZ_STAMP(PH_T1);
-    tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM, 2>(nrp, sl, z0, red, rpar);
+    tz_block_reduce3<RED_MAXU, RED_SUM, RED_SUM, 2>(nrp, sl, z0, red, rpar);
     TZ_STAMP(PH_T2);
     const double mu = sl * pi.inv_mi;
     nrp *= tz_recip(red[13]);
@@ -1213,7 +1287,7 @@ retry_solve:
     TZ_FRESH_T();
     if (rlev != 0) {
       const double rx = (rlev == 1) ? 1e-9 : (rlev == 2) ? 1e-6 : (rlev == 3) ? 1e-3 : 1.0;
-      for (int c = t; c < nz; c += TZ_THREADS) {
+      TZ_COLS(c, nz) {
         const int I = c >> 2, i = c & 3;
         Hq[TT ? (size_t)(((I * (I + 1)) >> 1) + I) * p.TS + 5 * i : (size_t)tz_hidx(c, c)] += rx;
       }
@@ -1256,7 +1330,7 @@ retry_solve:
       if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part2);
       else tz_ell_gemvT_part(p, vin, pl);
       __syncthreads();
-      for (int c = t; c < nzp; c += TZ_THREADS) {
+      TZ_COLS(c, nzp) {
         const double pxq = (c < nz) ? part2[c] + qv[c] : 0.0;
         rdv[c] = pxq;
         r1v[c] = (c < nz) ? -pxq - tz_ell_colsum(pl, cseg) : 0.0;
@@ -1296,7 +1370,7 @@ retry_solve:
     }
     // z4: complementarity after the affine step, summed for the full step in the same reduction as the step lengths: when the full
     // step is feasible (the usual case from a warm start) that sum is the one wanted, otherwise it is formed again with ap, ad
-    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM>(mp, md, z4, red, rpar);
+    tz_block_reduce3<RED_MAXU, RED_MAXU, RED_SUM>(mp, md, z4, red, rpar);
     const double ap = tz_recip(fmax(1.0, mp)), ad = tz_recip(fmax(1.0, md));
     double muaff = z4;
     if (mp > 1.0 || md > 1.0) {
@@ -1311,7 +1385,7 @@ retry_solve:
       // the Newton (predictor) step is already (almost) a full step and kills complementarity: take it, skip the corrector
       const double mmA = fmax(mp, md);
       const double alphaA = (mmA > sfr) ? sfr * tz_recip(mmA) : 1.0;
-      for (int c = t; c < nz; c += TZ_THREADS) xv[c] += alphaA * dxv[c];
+      TZ_COLS(c, nz) xv[c] += alphaA * dxv[c];
       TZ_ROWS(k, r) { s_[k] += alphaA * ds_[k]; l_[k] += alphaA * dl_[k]; TZ_ADD_GX(k, r, alphaA * g_[k]); }
       __syncthreads();
       continue;
@@ -1329,7 +1403,7 @@ retry_solve:
     __builtin_amdgcn_s_setprio(0);
     if (!wave0) tz_ell_gemvT_part(p, vin, pl);
     __syncthreads();
-    for (int c = t; c < nzp; c += TZ_THREADS) r1v[c] = (c < nz) ? -rdv[c] - tz_ell_colsum(pl, cseg) : 0.0;
+    TZ_COLS(c, nzp) r1v[c] = (c < nz) ? -rdv[c] - tz_ell_colsum(pl, cseg) : 0.0;
     __syncthreads();
     TZ_STAMP(PH_GEMVT);
     if constexpr (TT) TZ_TT_SOLVE(p, Hq, dinv, r1v, tmpz, dxv);
@@ -1348,10 +1422,10 @@ retry_solve:
       ms = fmax(ms, -ds * is_[k]);
       ml = fmax(ml, -dl * il_[k]);
     }
-    tz_block_reduce3<RED_MAX, RED_MAX, RED_SUM, 2>(ms, ml, z3, red, rpar);
+    tz_block_reduce3<RED_MAXU, RED_MAXU, RED_SUM, 2>(ms, ml, z3, red, rpar);
     const double mm = fmax(ms, ml);
     const double alpha = (mm * 1.0 > sfr) ? sfr * tz_recip(mm) : 1.0;      // min(1, sfr * min_i(-v_i/dv_i))
-    for (int c = t; c < nz; c += TZ_THREADS) xv[c] += alpha * dxv[c];
+    TZ_COLS(c, nz) xv[c] += alpha * dxv[c];
     TZ_ROWS(k, r) { s_[k] += alpha * ds_[k]; l_[k] += alpha * dl_[k]; TZ_ADD_GX(k, r, alpha * g_[k]); }
     __syncthreads();
   }
@@ -1362,8 +1436,7 @@ retry_solve:
     attempt = 1; src = 0;
     __syncthreads();
     if (t == 0) flag[0] = 0;
-    for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
-    for (int r = t; r < mip + 4; r += TZ_THREADS) vin[r] = (r < mi) ? 1.0 : 0.0;
+    TZ_COLS(c, nzp) xv[c] = 0.0;
     TZ_ROWS(k, r) { s_[k] = 1.0; l_[k] = 1.0; }
     __syncthreads();
     goto retry_solve;
@@ -1386,7 +1459,7 @@ retry_solve:
     double gmax = fabs(tz_ell_colsum(pl, cseg));
     tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM, 2>(gmax, hy, z2, red, rpar);
     if (lm_ok && hy < -1e-6 && gmax <= 1e-6 * fmax(1.0, -hy)) status = 3;
-    for (int c = t; c < nzp; c += TZ_THREADS) xv[c] = 0.0;
+    TZ_COLS(c, nzp) xv[c] = 0.0;
     px_in_part = false;
     __syncthreads();
   }
@@ -1395,7 +1468,7 @@ retry_solve:
   asm volatile("" : "+s"(kpe));
   const IpmParams& pe = *(const IpmParams*)kpe;
   if (step == nsteps - 1) {                 // what a later launch (or the host) reads: solution, multipliers, status
-    for (int c = t; c < nz; c += TZ_THREADS) pe.x[(size_t)b * nz + c] = xv[c];
+    TZ_COLS(c, nz) pe.x[(size_t)b * nz + c] = xv[c];
     TZ_ROWS(k, r) { pe.s[(size_t)b * mi + r] = s_[k]; pe.lam[(size_t)b * mi + r] = l_[k]; }
     if (t == 0) {
       pe.status[b] = status; pe.iters[b] = it;
@@ -1415,6 +1488,37 @@ retry_solve:
     const double* ec = tbl + (F.tube.pmax + 1) * n * n + (F.tube.pmax > 0 ? F.tube.pmax : 1) * (n + m) * n;   // LDS constants, see above
     const double *cA = ec, *cB = ec + n * n, *cK = cB + n * m, *cr1 = cK + n * m, *cR2 = cr1 + n, *cPhi = cR2 + n * n, *cGam = cPhi + n * n, *cDz = cGam + n * nv;
     const bool want_cost = F.cost_step != 0 || step == nsteps - 1;      // a cost that the next step overwrites is not formed
+    if (F.lean_epilogue != 0 && !want_cost && !F.fin.v && !F.fin.xbar) {
+      // a step inside a multi-step launch that reports neither cost nor v / xbar: everything the next step needs -- u = K e + v[0],
+      // x+ = A x + B u + w, xbar+ = Phi_1 xbar + Gam_1 v[0], e+ -- is n (n + m) products: one wave, no workgroup barrier inside
+      if (skip) __syncthreads();                         // x was zeroed after the last barrier
+      if (t == 0 && status != 0 && F.plant.sticky && F.plant.sticky[b] == 0) F.plant.sticky[b] = status;
+      if (t < 64) {
+        const PlantParams& Q = F.plant;
+        double xn = 0.0, xb = 0.0;
+        if (t < n) {
+          xn = stl[3 * TZ_NMAX + t];                          // w of this step (fetched in the prologue)
+          for (int j = 0; j < n; ++j) { xn += cA[t * n + j] * stl[j]; xb += cPhi[t * n + j] * x0[j]; }
+          for (int j = 0; j < m; ++j) {
+            const double v0 = cDz[j] * xv[F.fin.vpos ? F.fin.vpos[j] : j];
+            double u = v0;
+            for (int i = 0; i < n; ++i) u += cK[j * n + i] * stl[2 * n + i];
+            xn += cB[t * m + j] * u; xb += cGam[t * nv + j] * v0;
+            if (t == 0 && Q.u_out) Q.u_out[(size_t)b * Q.u_stride + (size_t)step * F.u_step + j] = u;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // every lane has read the old state before any lane overwrites it
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (t < n) {
+          stl[t] = xn; stl[n + t] = xb; stl[2 * n + t] = xn - xb;
+          if (Q.x_out) Q.x_out[(size_t)b * Q.x_stride + (size_t)step * F.x_step + t] = xn;
+        }
+      }
+      __syncthreads();                          // the next step's tube pass reads the state
+      TZ_STAMP(PH_EPILOGUE);
+      continue;
+    }
     __syncthreads();
     if (want_cost && !px_in_part) tz_gemvT_partial<NCG>(p.P, p.nP, nzp, xv, part);
     if (F.fin.recy) {                                    // equality rows eliminated by the host: v is an affine map of (xbar0, x)
@@ -1430,7 +1534,7 @@ retry_solve:
     TZ_STAMP(PH_EPI_A);
     double acc = 0.0, z1 = 0.0, z2 = 0.0;
     if (want_cost) {
-      for (int c = t; c < nz; c += TZ_THREADS) acc += xv[c] * (0.5 * (px_in_part ? part[c] : tz_gemvT_get(part, nzp, c)) + qv[c]);
+      TZ_COLS(c, nz) acc += xv[c] * (0.5 * (px_in_part ? part[c] : tz_gemvT_get(part, nzp, c)) + qv[c]);
       tz_block_reduce3<RED_SUM, RED_SUM, RED_SUM, 1>(acc, z1, z2, red, rpar);
     }
     if (t == 0 && !want_cost) { if (status != 0 && F.plant.sticky && F.plant.sticky[b] == 0) F.plant.sticky[b] = status; }
@@ -1498,5 +1602,6 @@ retry_solve:
   }
 #undef TZ_STAMP
 #undef TZ_ROWS
+#undef TZ_COLS
 #undef TZ_FRESH_T
 }

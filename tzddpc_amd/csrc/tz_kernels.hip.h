@@ -24,11 +24,19 @@
 #define TZ_MMAX 8          // K0 (tz_identify.hip.h) and the gain kernels (tz_gain.hip.h) keep their own limits of 8 / 4
 
 // Affine map rows over theta in ELL form: entry e of row r at [e * rows + r] (coalesced over rows), W entries per row, rows
-// with fewer non-zeros padded with (0.0, column 0).  No row pointers: every load of a row is independent of the others.
+// with fewer non-zeros padded with (0.0, column 0).  No row pointers: every load of a row is independent of the others.  An entry
+// is one 16-byte record (value, byte offset of the theta entry, zero): one vector-memory instruction per non-zero.
+struct __attribute__((aligned(16))) TzEllEnt { double val; unsigned off; unsigned pad; };
+typedef double tz_d2 __attribute__((ext_vector_type(2)));
+// byte offset of the input entry: both halves of the record's second double are used (the second is zero), so that the record stays
+// ONE 16-byte load (the compiler splits a load of which only 12 bytes are consumed into two); base + off + pad is one v_add3_u32
+__device__ inline unsigned tz_ell_off(double y) {
+  const unsigned long long w = __builtin_bit_cast(unsigned long long, y);
+  return (unsigned)w + (unsigned)(w >> 32);
+}
 struct TzCsr {
   int rows, W;
-  const int* col;
-  const double* val;
+  const TzEllEnt* ent;
   const double* c0;
 };
 
@@ -61,12 +69,12 @@ __device__ inline double tz_quad_xor(double v) {                       // DPP qu
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 // All nt threads of the workgroup (tid) work on trajectory b.  aL: pmax * n doubles of LDS scratch; th: ntheta doubles (LDS or
-// global).  Contains one workgroup barrier; the caller adds another before th is read by other threads.
-// NC, MC: dim_x, dim_u known at compile time (0: taken from p) -- the index divisions become shifts / multiplies and the dot
+// global).  Two stages with a workgroup barrier between them (tz_tube_block); the caller adds another before th is read by other
+// threads.  NC, MC: dim_x, dim_u known at compile time (0: taken from p) -- the index divisions become shifts / multiplies and the dot
 // products unroll; power: p.power or a copy of it in LDS.
 template <int NC = 0, int MC = 0>
-__device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, const double* Ttab, const int* power, const double* xbar0, const double* e0, double* aL, double* th, int tid, int nt) {
-  const int n = NC ? NC : p.n, m = MC ? MC : p.m, hs = 2 * n + m;
+__device__ inline void tz_tube_stage1(const TubeParams& p, const double* CKpow, const double* xbar0, const double* e0, double* aL, double* th, int tid, int nt) {
+  const int n = NC ? NC : p.n;
   for (int e = tid; e < p.pmax * n; e += nt) {
     const double* M = CKpow + (size_t)e * n;              // row i of C_K^l with e = l n + i
     double a = 0.0;
@@ -74,7 +82,10 @@ __device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, c
     aL[e] = fabs(a);
   }
   if (tid < n) { const double x0 = xbar0[tid]; th[tid] = x0; th[n + tid] = fabs(x0); }
-  __syncthreads();
+}
+template <int NC = 0, int MC = 0>
+__device__ inline void tz_tube_stage2(const TubeParams& p, const double* CKpow, const double* Ttab, const int* power, const double* e0, const double* aL, double* th, int tid, int nt) {
+  const int n = NC ? NC : p.n, m = MC ? MC : p.m, hs = 2 * n + m;
   for (int e = tid; e < p.N * n; e += nt) {                      // centres c_k = C_K^power[k] e0
     const int k = e / n, i = e - k * n;
     const double* M = CKpow + ((size_t)power[k] * n + i) * n;
@@ -96,6 +107,12 @@ __device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, c
     a += tz_quad_xor<0x4E>(a);
     if (sub == 0) th[2 * n + k * hs + n + comp] = a;
   }
+}
+template <int NC = 0, int MC = 0>
+__device__ inline void tz_tube_block(const TubeParams& p, const double* CKpow, const double* Ttab, const int* power, const double* xbar0, const double* e0, double* aL, double* th, int tid, int nt) {
+  tz_tube_stage1<NC, MC>(p, CKpow, xbar0, e0, aL, th, tid, nt);
+  __syncthreads();
+  tz_tube_stage2<NC, MC>(p, CKpow, Ttab, power, e0, aL, th, tid, nt);
 }
 
 __global__ __launch_bounds__(64) void tz_tube_kernel(TubeParams p) {
@@ -120,12 +137,16 @@ struct AffineParams {
 #define TZ_ELL_REG 8
 __device__ inline double csr_row(const TzCsr& M, int r, const double* th) {
   double acc = M.c0[r];
-  double v[TZ_ELL_REG]; int c[TZ_ELL_REG];
+  const char* tb = reinterpret_cast<const char*>(th);
+  tz_d2 v[TZ_ELL_REG];
 #pragma unroll
-  for (int e = 0; e < TZ_ELL_REG; ++e) { v[e] = 0.0; c[e] = 0; if (e < M.W) { v[e] = M.val[(size_t)e * M.rows + r]; c[e] = M.col[(size_t)e * M.rows + r]; } }
+  for (int e = 0; e < TZ_ELL_REG; ++e) { v[e] = tz_d2{0.0, 0.0}; if (e < M.W) v[e] = *reinterpret_cast<const tz_d2*>(M.ent + (size_t)e * M.rows + r); }
 #pragma unroll
-  for (int e = 0; e < TZ_ELL_REG; ++e) if (e < M.W) acc += v[e] * th[c[e]];
-  for (int e = TZ_ELL_REG; e < M.W; ++e) acc += M.val[(size_t)e * M.rows + r] * th[M.col[(size_t)e * M.rows + r]];
+  for (int e = 0; e < TZ_ELL_REG; ++e) if (e < M.W) acc += v[e].x * *reinterpret_cast<const double*>(tb + tz_ell_off(v[e].y));
+  for (int e = TZ_ELL_REG; e < M.W; ++e) {
+    const tz_d2 q = *reinterpret_cast<const tz_d2*>(M.ent + (size_t)e * M.rows + r);
+    acc += q.x * *reinterpret_cast<const double*>(tb + tz_ell_off(q.y));
+  }
   return acc;
 }
 
@@ -178,6 +199,8 @@ struct PlantParams {
 // tube -> parameter maps -> solve -> recovery / objective -> plant update in one launch; theta, q, h stay in LDS / registers).
 struct FuseParams {
   int on;
+  int lean_epilogue;                // xbar[1] depends on v[0] only and v is a scaled copy of x (no equality elimination): the recovery and the plant
+                                    // update of a step that reports no cost / v / xbar are done by one wave without workgroup barriers
   int npar, ntheta;
   int nsteps, warm_steps;           // closed-loop steps done by this launch; warm_steps: step k+1 starts from the solution of step k
   size_t w_step, u_step, x_step, cost_step;   // element offsets per step into plant.w / plant.u_out / plant.x_out / fin.cost

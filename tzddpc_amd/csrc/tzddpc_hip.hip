@@ -62,7 +62,7 @@ struct DevBuf {
 // Balanced lane-ELL of a sparse matrix for the matrix-vector products of tz_ipm_kernel (TzEll in tz_ipm.hip.h).
 // outs[o] = (index, value) pairs of output o; NL physical lanes per pass; the virtual lane count VL is a multiple of NL.
 struct DevEll {
-  DevBuf<double> val; DevBuf<unsigned short> idx; DevBuf<int> seg;
+  DevBuf<TzEllEnt> ent; DevBuf<int> seg;
   int L = 1, VL = 0;
   hipError_t build(const std::vector<std::vector<std::pair<int, double>>>& outs, int NL, int VLwant) {
     VL = ((std::max(VLwant, 1) + NL - 1) / NL) * NL;
@@ -73,8 +73,7 @@ struct DevEll {
       for (auto& o : outs) lanes += (o.size() + L - 1) / L;
       if (lanes <= (size_t)VL) break;
     }
-    std::vector<double> v((size_t)VL * L, 0.0);
-    std::vector<unsigned short> ix((size_t)VL * L, 0);
+    std::vector<TzEllEnt> v((size_t)VL * L, TzEllEnt{0.0, 0u, 0u});
     std::vector<int> sg(std::max<size_t>(outs.size(), 1), 0);
     int lane = 0;
     for (size_t o = 0; o < outs.size(); ++o) {
@@ -83,40 +82,38 @@ struct DevEll {
       for (size_t e = 0; e < outs[o].size(); ++e) {
         const int vl = lane + (int)(e / L), slot = (int)(e % L);
         const size_t pos = ((size_t)(vl / NL) * L + slot) * NL + (vl % NL);
-        v[pos] = outs[o][e].second; ix[pos] = (unsigned short)outs[o][e].first;
+        v[pos] = TzEllEnt{outs[o][e].second, (unsigned)outs[o][e].first * 8u, 0u};
       }
       lane += cnt;
     }
     hipError_t e;
-    if ((e = val.upload(v)) != hipSuccess) return e;
-    if ((e = idx.upload(ix)) != hipSuccess) return e;
+    if ((e = ent.upload(v)) != hipSuccess) return e;
     return seg.upload(sg);
   }
-  TzEll view() const { return TzEll{L, VL, val.p, idx.p, seg.p}; }
-  void swap(DevEll& o) { val.swap(o.val); idx.swap(o.idx); seg.swap(o.seg); std::swap(L, o.L); std::swap(VL, o.VL); }
+  TzEll view() const { return TzEll{L, VL, ent.p, seg.p}; }
+  void swap(DevEll& o) { ent.swap(o.ent); seg.swap(o.seg); std::swap(L, o.L); std::swap(VL, o.VL); }
 };
 
 struct DevCsr {          // device copy of a tz_affmap (CSR in the ABI) re-laid out as ELL, see TzCsr
-  DevBuf<int> col;
-  DevBuf<double> val, c0;
+  DevBuf<TzEllEnt> ent;
+  DevBuf<double> c0;
   int rows = 0, W = 1;
   // perm (may be null): device row i is row perm[i] of the map
   hipError_t upload(const tz_affmap& m, const int* perm = nullptr) {
     rows = m.rows; W = 1;
     for (int r = 0; r < m.rows; ++r) W = std::max(W, m.ptr[r + 1] - m.ptr[r]);
-    std::vector<int> ce((size_t)W * std::max(rows, 1), 0);
-    std::vector<double> ve((size_t)W * std::max(rows, 1), 0.0), cc((size_t)std::max(rows, 1), 0.0);
+    std::vector<TzEllEnt> ve((size_t)W * std::max(rows, 1), TzEllEnt{0.0, 0u, 0u});
+    std::vector<double> cc((size_t)std::max(rows, 1), 0.0);
     for (int i = 0; i < m.rows; ++i) {
       const int r = perm ? perm[i] : i;
       cc[i] = m.c0[r];
-      for (int e = m.ptr[r]; e < m.ptr[r + 1]; ++e) { ce[(size_t)(e - m.ptr[r]) * rows + i] = m.col[e]; ve[(size_t)(e - m.ptr[r]) * rows + i] = m.val[e]; }
+      for (int e = m.ptr[r]; e < m.ptr[r + 1]; ++e) ve[(size_t)(e - m.ptr[r]) * rows + i] = TzEllEnt{m.val[e], (unsigned)m.col[e] * 8u, 0u};
     }
     hipError_t e;
-    if ((e = col.upload(ce)) != hipSuccess) return e;
-    if ((e = val.upload(ve)) != hipSuccess) return e;
+    if ((e = ent.upload(ve)) != hipSuccess) return e;
     return c0.upload(cc.data(), (size_t)m.rows);
   }
-  TzCsr view() const { return TzCsr{rows, W, col.p, val.p, c0.p}; }
+  TzCsr view() const { return TzCsr{rows, W, ent.p, c0.p}; }
 };
 
 enum { K_TUBE = 0, K_IPM = 1, K_FINISH = 2, K_PLANT = 3, K_COUNT = 4 };
@@ -205,7 +202,8 @@ struct tz_problem {
   bool ksplit = false;         // Gram by k-split (Tz <= TZ_KS_TZ; TZ_KSPLIT=0 keeps the item plan)
   bool fuse_enabled = true;    // closed-loop steps in one launch (TZ_PLAN_UNFUSED: four kernels per step, same arithmetic)
   bool staircase = false;      // tile-triangle class: variables in time order, rows by last non-zero column (library-internal)
-  bool toeplitz = false;       // G x / G'v as block-Toeplitz convolutions over the horizon (tz_conv.hip.h)
+  bool toeplitz = false;       // G x / G'v as block-Toeplitz convolutions over the horizon (not built: see DESIGN.md)
+  bool lean_epilogue = false;  // FuseParams::lean_epilogue
   struct tz_genstack* tube_stack = nullptr;   // literal problems: decision-independent generators, evaluated per solve (not owned)
   DevBuf<double> ts_zeta, ts_c, ts_rx, ts_ru;  int ts_cap = 0;
   int maxr = 1, ncg = 1;
@@ -316,7 +314,7 @@ int launch_step_fused(tz_problem* p, int B, double* d_x, double* d_xbar, double*
   Timer tm(p, K_IPM);
   IpmParams ip = ipm_params(p, B, d_status, p->iters.p, warm, true);
   FuseParams& F = ip.F;
-  F.on = 1; F.npar = p->npar; F.ntheta = p->ntheta;
+  F.on = 1; F.npar = p->npar; F.ntheta = p->ntheta; F.lean_epilogue = p->lean_epilogue ? 1 : 0;
   F.nsteps = nsteps; F.warm_steps = p->warm_enabled ? 1 : 0; ip.warm_steps = F.warm_steps;
   F.w_step = ss.w; F.u_step = ss.u; F.x_step = ss.x; F.cost_step = ss.cost;
   F.tube = TubeParams{B, p->n, p->m, p->N, p->pmax, p->ntheta, p->CKpow.p, p->Ttube.p, p->power.p, d_xbar, d_e, nullptr, nullptr};
@@ -910,6 +908,11 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
     std::vector<double> ry((size_t)nv * nz);
     for (int c = 0; c < nv; ++c) for (int k = 0; k < nz; ++k) ry[(size_t)c * nz + k] = d->rec_y[(size_t)c * nz + permc[k]];
     TZ_HIP(p->recy.upload(ry)); TZ_HIP(p->rec0.upload(d->rec_c0, (size_t)nv)); TZ_HIP(p->recx.upload(d->rec_x0, (size_t)nv * d->n));
+  }
+  {                                                                      // xbar[1] = Phi_1 xbar0 + Gam_1 v with Gam_1 confined to v[0] (it is A xbar0 + B v[0], reference :166-170)
+    bool only_v0 = !(d->rec_y || d->rec_c0 || d->rec_x0);
+    for (int i = 0; i < d->n && only_v0; ++i) for (int c = d->m; c < nv; ++c) if (d->Gam[((size_t)d->n + i) * nv + c] != 0.0) { only_v0 = false; break; }
+    p->lean_epilogue = only_v0;
   }
   TZ_HIP(p->Phi.upload(d->Phi, (size_t)(d->N + 1) * d->n * d->n));
   TZ_HIP(p->Gam.upload(d->Gam, (size_t)(d->N + 1) * d->n * d->N * d->m));
