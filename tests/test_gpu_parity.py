@@ -333,7 +333,7 @@ def test_single_wave_factor_path_equals_four_wave_path(built):
         fast, (A, B, zon) = common.gpu_controller(case)
         slow, _ = common.gpu_controller(case, plan_flags=native.TZ_PLAN_GENERAL_CHOLESKY | native.TZ_PLAN_ITEM_GRAM)
         pf, ps = fast._native.plan_info(), slow._native.plan_info()
-        assert pf["chol1"] and pf["ksplit"] and not ps["chol1"] and not ps["ksplit"]
+        assert pf["chol1"] and pf["ksplit"] == (fast.qp.nz <= 40) and not ps["chol1"] and not ps["ksplit"]
         slow._native.set_warm_shift(fast.warm_shift_policy)      # same policy on both sides (the calibration is per build)
         slow._native.set_warm_push(1e-8, fast.warm_push_gain, fast.warm_push_cap)
         noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
@@ -423,7 +423,7 @@ def test_infeasible_trajectories_are_flagged_not_fatal(built):
     for r in (a, b):
         assert (r["status"][bad] == 3).all() and (r["status"][~bad] == 0).all()
         assert np.isinf(r["cost"][bad, 0]).all() and np.isfinite(r["cost"][~bad]).all()
-    np.testing.assert_allclose(a["x"][~bad], b["x"][~bad], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(a["x"][~bad], b["x"][~bad], rtol=0, atol=1e-9)          # (xbar[1] on one wave in the fused step: see test_fused_step_equals_four_kernel_step)
     np.testing.assert_allclose(a["x"][bad], b["x"][bad], rtol=1e-12, atol=1e-9)
     good_alone = fused.simulate_batch(x0[~bad], noise[~bad], A, B)
     np.testing.assert_array_equal(good_alone["x"], a["x"][~bad])          # trajectories do not influence each other

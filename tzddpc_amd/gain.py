@@ -135,8 +135,8 @@ def compute_theta(Mdata: MatrixZonotope, A0: np.ndarray, B0: np.ndarray, toleran
         An, Bn = compute_A_B(Mdata, Kn, initial_points, device=device, rng=rng)         # :78
         lambda_max = max(spectral_radius(An + Bn @ Kn), spectral_radius(A0 + B0 @ Kn))  # :80
         if verbose:
-            print(f"[Iteration {iteration}] Closed loop spectral radius: {lambda_init}->{lambda_max} - "
-                  f"Adversarial spectral radius: {lambda_adv} - K {Kn.flatten()}")
+            print(f"gain synthesis, pass {iteration}: rho(A + B K) {lambda_init:.6f} before the LMI point, {lambda_adv:.6f} after, "
+                  f"{lambda_max:.6f} on the adversarial pair; K = {np.array2string(Kn.ravel(), precision=6)}")
         if np.abs(lambda_max - prev_lambda_max) < tolerance or lambda_max < 1:          # :82
             break
         iteration += 1
