@@ -283,9 +283,11 @@ int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, dou
  * finish in one iteration (up to tz_problem_set_warm_quiet of them).  Which one pays depends on the problem (double
  * integrator N=20: 1; pulley: 0) -- the Python layer calibrates it on a short simulated closed loop at build time. */
 int tz_problem_set_warm_shift(tz_problem* p, int32_t policy);
-/* Policies k >= 2 leave the shifted regime again after `quiet_steps` shifted steps in a row that needed one iteration (default 16,
- * 0: never): near the steady state an unshifted start is as good and keeps G x of the previous iterate (one pass over G less per
- * step: +4.7 % on the double integrator N=40 in steady state, measured); leaving earlier costs iterations in the late transient. */
+/* Policies k >= 2 leave the shifted regime after `quiet_steps` shifted steps in a row that needed at most one iteration (default 16,
+ * 0: never) and REST: the previous solution is taken as it is (no shift, G x of the previous iterate kept: the cheapest step there
+ * is) for as long as such a start needs no iteration at all; the first resting step that needs one sends the trajectory back to the
+ * shifted regime.  (Until round 4 a trajectory came back only after a step of >= k iterations, and a loop that had not settled
+ * when its budget ran out took one Newton step in every step from then on.) */
 int tz_problem_set_warm_quiet(tz_problem* p, int32_t quiet_steps);
 
 /* Stopping test of the interior point, relative to the `tol` of the descriptor: scaled residuals <= res_factor * tol and

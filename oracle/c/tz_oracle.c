@@ -420,10 +420,14 @@ static int tzo_simulate_core(const tzo_desc* d, int B, int T, const double* x0, 
       for (int t = 0; t < T; ++t) {
         int32_t st, it; double c;
         int wmode = prev_ok ? ((t & 7) ? 2 : 1) : 0;               /* x / s / lam (and G x) of the previous step live on in wk */
-        const int quiet_run = was_shifted && prev_it <= 1;
-        const int nquiet = quiet_run ? was_shifted : 0;              /* was_shifted = 1 + quiet shifted steps so far */
-        if (prev_ok && S->srow && (d->shift_policy == 1 || (d->shift_policy >= 2 && (prev_it >= d->shift_policy || (quiet_run && (d->shift_quiet == 0 || nquiet <= d->shift_quiet)))))) wmode = 3;
-        was_shifted = (wmode == 3) ? 1 + nquiet : 0;
+        /* was_shifted: 1 + q = the last start was shifted after q quiet (<= 1 iteration) shifted steps; 0 = not shifted; -1 = not shifted
+         * because the quiet budget ran out ("rest"): the unshifted start is kept for as long as it needs no iteration at all (a settled
+         * loop: no shift, no G x) and the shifted regime is re-entered the moment it needs one */
+        const int quiet_run = was_shifted > 0 && prev_it <= 1;
+        const int nquiet = quiet_run ? was_shifted : 0;
+        const int back = was_shifted < 0 && prev_it >= 1;
+        if (prev_ok && S->srow && (d->shift_policy == 1 || (d->shift_policy >= 2 && (prev_it >= d->shift_policy || back || (quiet_run && (d->shift_quiet == 0 || nquiet <= d->shift_quiet)))))) wmode = 3;
+        was_shifted = (wmode == 3) ? 1 + nquiet : ((prev_ok && ((quiet_run && d->shift_policy >= 2) || (was_shifted < 0 && !back))) ? -1 : 0);
         solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk, wmode);
         prev_it = it;
         if (iters_out) iters_out[(size_t)b * T + t] = it;

@@ -18,14 +18,51 @@ CUTS = {
     6: ("    TZ_STAMP(PH_T2);\n", "before"),                                                                # + loop top: rp, reduction        (in loop)
     7: ("      TZ_STAMP(PH_GEMVT);\n      if (!(nrd == nrd))", "before"),                                   # + exact dual residual            (in loop)
     8: ("  work_s += 1;\n", "before"),                                                                      # + loop exit, counters
+    9: ("      TZ_STAMP(PH_GEMVT);\n      if (!(nrd == nrd))", "before"),                                   # the whole quiet step: every test accepted, epilogue run
 }
 
 
+# second family: every step from the 30th on is made to take exactly one Newton iteration (the acceptance of the starting point is
+# switched off), and stops at a checkpoint inside that iteration
+FORCE = ("      if (nrd <= pi.tol_res && nrp <= pi.tol_res && mu <= pi.mu_tol) { status = 0; px_in_part = true; break; }",
+         "      if (nrd <= pi.tol_res && nrp <= pi.tol_res && mu <= pi.mu_tol && !(fused && step >= 30 && it == 0)) { status = 0; px_in_part = true; break; }")
+ITER_CUTS = {
+    10: ("    TZ_STAMP(PH_TOP);\n", "before", 1),          # quiet prefix + rejected test + weights staged
+    11: ("    TZ_STAMP(PH_FORM);\n", "before", 1),         # + Gram
+    12: ("    TZ_FRESH_T();\n    if constexpr (TT) TZ_TT_SOLVE(p, Hq, dinv, r1v, tmpz, dxv);", "before", 1),   # + Cholesky || right-hand side || forward substitution
+    13: ("    TZ_STAMP(PH_SOLVE);\n    tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);\n    TZ_STAMP(PH_GEMV);\n    __builtin_amdgcn_s_setprio(TZ_PRIO_ELEM);\n    // step to the boundary", "before", 1),   # + backward substitution
+    14: ("    __builtin_amdgcn_s_setprio(TZ_PRIO_ELEM);\n    // step to the boundary", "before", 1),              # + G dx
+    15: ("    double sigma = muaff * tz_recip(mu); sigma = sigma * sigma * sigma;", "before", 1),                  # + step lengths (the predictor was not taken as the step)
+    16: None,                                                                                                      # whole step with one forced iteration
+}
+
+
+def patched_iter(k):
+    s = open(os.path.join(SRC, "tz_ipm.hip.h")).read()
+    assert s.count(FORCE[0]) == 1
+    s = s.replace(FORCE[0], FORCE[1])
+    if ITER_CUTS[k] is None:
+        return s
+    anchor, where, _ = ITER_CUTS[k]
+    assert s.count(anchor) == 1, (k, s.count(anchor))
+    code = "    if (fused && step >= 30 && it == 0) { status = 0; it = 0; tz_cut = true; break; }\n"
+    s = s.replace(anchor, code + anchor)
+    a = "  for (it = 0; it < pk.max_iter && status == 1; ++it) {\n"
+    s = s.replace(a, "  bool tz_cut = false;\n" + a)
+    b = "  TZ_FRESH_T();\n  work_f = __builtin_amdgcn_readfirstlane(work_f + it"
+    s = s.replace(b, "  if (tz_cut) { __syncthreads(); continue; }\n" + b)
+    return s
+
+
 def patched(k):
+    if k >= 10:
+        return patched_iter(k)
     s = open(os.path.join(SRC, "tz_ipm.hip.h")).read()
     anchor, where = CUTS[k]
     assert s.count(anchor) == 1, (k, s.count(anchor))
     inloop = k in (6, 7)
+    if k == 9:                                             # accept whatever the starting point is: no Newton iteration after step 30, the rest of the step as it is
+        return s.replace(anchor, "      if (fused && step >= 30) { status = 0; px_in_part = true; break; }\n" + anchor)
     code = ("    if (fused && step >= 30) { status = 0; it = 0; tz_cut = true; break; }\n" if inloop
             else "  if (fused && step >= 30) { status = 0; it = 0; __syncthreads(); continue; }\n")
     s = s.replace(anchor, anchor + code if where == "after" else code + anchor)
@@ -44,7 +81,7 @@ def main():
     os.makedirs(out, exist_ok=True)
     flags = ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc", "-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-disable-machine-licm"]
     procs = []
-    for k in CUTS:
+    for k in list(CUTS) + list(ITER_CUTS):
         base = f"{TMP}{k}"
         d = os.path.join(base, "tzddpc_amd", "csrc")                      # the source includes ../../include/tzddpc.h
         shutil.rmtree(base, ignore_errors=True); shutil.copytree(SRC, d); shutil.copytree(os.path.join(ROOT, "include"), os.path.join(base, "include"))
@@ -57,7 +94,7 @@ def main():
                 assert pr.wait() == 0, kk
     for kk, pr in procs:
         assert pr.wait() == 0, kk
-    print("built", sorted(CUTS))
+    print("built", sorted(CUTS) + sorted(ITER_CUTS))
 
 
 if __name__ == "__main__":

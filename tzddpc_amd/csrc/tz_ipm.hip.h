@@ -1061,13 +1061,20 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   if (fused && t < F.fin.n) wpre = F.plant.w[(size_t)b * F.plant.w_stride + (size_t)step * F.w_step + t];
   // warm-start policy of this step (uniform): the previous solution, optionally moved one step along the horizon (v_k <- v_{k+1} ...:
   // better in a transient, a matter of the problem otherwise -- tz_problem_set_warm_shift)
+  // was_shifted: 1 + q = the last start was shifted, after q quiet (<= 1 iteration) shifted steps; 0 = not shifted; -1 = not shifted because
+  // the quiet budget ran out ("rest", round 4): the unshifted start is kept for as long as it needs no iteration at all -- a settled loop:
+  // no shift, no G x, the cheapest step there is -- and the shifted regime is re-entered the moment a step needs one.  (Until round 4
+  // a trajectory that left the shifted regime came back only after a step of >= k iterations: a loop that was not settled yet then
+  // took one Newton step in EVERY step from the 17th quiet step on -- 0.51 factorisations per step in steps 30-130 of the headline
+  // problem instead of 0.01.)
   bool shifted = false;
   if (src != 0) {
     const int prev_it = (step == 0) ? pk.iters[b] : it;
-    const bool quiet_run = was_shifted != 0 && prev_it <= 1;
+    const bool quiet_run = was_shifted > 0 && prev_it <= 1;
     const int nquiet = quiet_run ? was_shifted : 0;                       // was_shifted - 1 quiet steps so far, this one included: was_shifted
-    shifted = pk.shift_policy == 1 || (pk.shift_policy >= 2 && (prev_it >= pk.shift_policy || (quiet_run && (pk.shift_quiet == 0 || nquiet <= pk.shift_quiet))));
-    was_shifted = shifted ? 1 + nquiet : 0;
+    const bool back = was_shifted < 0 && prev_it >= 1;
+    shifted = pk.shift_policy == 1 || (pk.shift_policy >= 2 && (prev_it >= pk.shift_policy || back || (quiet_run && (pk.shift_quiet == 0 || nquiet <= pk.shift_quiet))));
+    was_shifted = shifted ? 1 + nquiet : (((quiet_run && pk.shift_policy >= 2) || (was_shifted < 0 && !back)) ? -1 : 0);
   }
   // A step that starts from the previous step of the same launch (src == 2: x in LDS, lambda in registers) runs the warm start INSIDE the
   // barrier intervals of the prologue: the two halves of the horizon shift beside the two stages of the tube pass, the walk of G x
