@@ -542,7 +542,7 @@ def main(argv=None):
     def measure(x_start, warm, k, reps):
         """`reps` timed windows of k steps, each after a fresh start + `warm` untimed steps; barrier + synchronize on both sides,
         max over ranks."""
-        out = dict(windows=[], kern_ms=[], facts=[], solves=[], rank_ms=[], gathered=None, bad=torch.zeros(Bl, dtype=torch.int32, device=dev))
+        out = dict(windows=[], kern_ms=[], facts=[], solves=[], fmax=[], rank_ms=[], gathered=None, bad=torch.zeros(Bl, dtype=torch.int32, device=dev))
         for _ in range(reps):
             out["bad"] |= fresh_start(x_start, warm)
             nat.timing_enable(True)                                          # zeroes the event sums / work counters of the library
@@ -569,7 +569,7 @@ def main(argv=None):
             out["windows"].append(float(tmax.item()))
             ms, cnt = nat.timing_get(1)                                      # HIP events recorded by the library on its own stream around the launch
             work = nat.work_get()
-            out["kern_ms"].append(ms / max(cnt, 1)); out["facts"].append(work["factorizations"]); out["solves"].append(work["trajectory_solves"])
+            out["kern_ms"].append(ms / max(cnt, 1)); out["facts"].append(work["factorizations"]); out["solves"].append(work["trajectory_solves"]); out["fmax"].append(work["max_factorizations_one_trajectory"])
             out["bad"] |= (status != 0).int()
         nb = out["bad"].sum().to(torch.float64).reshape(1)
         if use_dist:
@@ -583,7 +583,9 @@ def main(argv=None):
         i = mm["med"]
         return {"value": total * k / mm["windows"][i], "unit": "MPC steps/s", "steps": k, "window_ms": mm["windows"][i] * 1e3,
                 "window_ms_all": [round(w * 1e3, 4) for w in mm["windows"]], "kernel_ms": mm["kern_ms"][i],
-                "ipm_factorizations_per_trajectory_step": mm["facts"][i] / max(mm["solves"][i], 1), "unsolved_trajectory_steps": mm["nbad"]}
+                "ipm_factorizations_per_trajectory_step": mm["facts"][i] / max(mm["solves"][i], 1),
+                "ipm_factorizations_slowest_trajectory": int(mm["fmax"][i]),      # all trajectories are resident at once: the launch lasts as long as this one
+                "unsolved_trajectory_steps": mm["nbad"]}
 
     fresh_start(x_same, W)
     _ = collect()                                                        # warm torch's copy / RCCL paths outside the timed region
@@ -626,7 +628,7 @@ def main(argv=None):
             "config": {"workload": f"{desc}; {Bl} closed-loop trajectories per GPU, {'complexity-script' if sysname in ('di_cc', 'di2in') else 'example'} zonotopes, "
                                    f"vertex-of-W noise PCG64(1000+i), all {K} timed steps in one launch",
                        "name": args.config, "trajectories_per_gpu": Bl, "horizon": horizon, "k0": k0, "nz": ctl.qp.nz, "rows": int(nat.mi),
-                       "ipm_factorizations_per_trajectory_step": iters_mean, "warm_start": os.environ.get("TZ_WARM", "1") != "0",
+                       "ipm_factorizations_per_trajectory_step": iters_mean, "ipm_factorizations_slowest_trajectory": int(head["fmax"][med]), "warm_start": os.environ.get("TZ_WARM", "1") != "0",
                        "warm_shift_policy": int(ctl.warm_shift_policy), "warm_push_gain": float(ctl.warm_push_gain), "warm_push_cap": (None if not np.isfinite(ctl.warm_push_cap) else float(ctl.warm_push_cap)), "mu_factor": float(ctl.mu_factor), "unsolved_trajectory_steps": head["nbad"],
                        "gathered_rows": int(head["gathered"].shape[0]), "world_size_read_back": (dist.get_world_size() if use_dist else 1),
                        "lds_bytes_per_workgroup": nat.plan_info()["lds_bytes"],

@@ -318,8 +318,10 @@ int tz_problem_reset_warm(tz_problem* p);
 int tz_timing_enable(tz_problem* p, int enable);
 int tz_timing_get(tz_problem* p, int kernel, double* total_ms, int64_t* launches);
 /* Work done by tz_ipm since tz_timing_enable(p, 1): number of Newton-matrix factorisations (Gram + Cholesky) summed over all
- * trajectories and launches, and number of trajectory solves.  Counted on the device by the kernel itself. */
-int tz_ipm_work_get(tz_problem* p, int64_t* factorizations, int64_t* trajectory_solves);
+ * trajectories and launches, number of trajectory solves, and (may be NULL) the largest number of factorisations any ONE trajectory
+ * did inside one launch -- with all trajectories resident at once a multi-step launch lasts as long as its slowest trajectory.
+ * Counted on the device by the kernel itself. */
+int tz_ipm_work_get(tz_problem* p, int64_t* factorizations, int64_t* trajectory_solves, int64_t* max_factorizations_one_trajectory);
 
 /* Static plan of tz_ipm for one trajectory and one interior-point iteration: number of
  * v_mfma_f64_4x4x4 instructions that carry useful tiles in the Gram formation (G'WG, block-sparse) and in

@@ -96,7 +96,7 @@ struct IpmParams {
   double warm_gain, warm_cap;    // warm point pushed into the cone by sigma = min(max(warm_floor, warm_gain * violation of the new rows), warm_cap)
   double aff_thr, aff_mu;        // predictor step taken as the step (no corrector solve) when it reaches aff_thr of the way to the
                                  // boundary un-damped and leaves mu_aff <= aff_mu * mu; aff_thr > 1 disables
-  unsigned long long* work;   // [0] += factorisations, [1] += solved trajectories (bench.py roofline accounting); may be null
+  unsigned long long* work;   // [0] += factorisations, [1] += trajectory solves, [2] = max over trajectories of the factorisations of one launch; may be null
   unsigned long long* prof;   // TZ_PROF=1: per-phase cycle sums of workgroup 0 (diagnostic; no output depends on it)
   FuseParams F;               // F.on != 0: whole closed-loop step in this launch (q, h, prestatus above are then unused)
 };
@@ -1481,7 +1481,7 @@ retry_solve:
       pe.status[b] = status; pe.iters[b] = it;
       if (pe.shift_policy >= 2) pe.shift_state[b] = was_shifted;
       if (pe.status_copy) pe.status_copy[b] = status;
-      if (pe.work) { atomicAdd(pe.work, (unsigned long long)work_f); atomicAdd(pe.work + 1, (unsigned long long)work_s); }
+      if (pe.work) { atomicAdd(pe.work, (unsigned long long)work_f); atomicAdd(pe.work + 1, (unsigned long long)work_s); atomicMax(pe.work + 2, (unsigned long long)work_f); }
     }
   }
   TZ_STAMP(PH_ELEM);

@@ -1113,8 +1113,8 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
     p->step_frac = sf;
   }
   if (p->prof) { TZ_HIP(p->prof_buf.alloc(PH_COUNT + 16)); TZ_HIP(hipMemset(p->prof_buf.p, 0, (PH_COUNT + 16) * sizeof(unsigned long long))); }
-  TZ_HIP(p->work_buf.alloc(2));
-  TZ_HIP(hipMemset(p->work_buf.p, 0, 2 * sizeof(unsigned long long)));
+  TZ_HIP(p->work_buf.alloc(3));
+  TZ_HIP(hipMemset(p->work_buf.p, 0, 3 * sizeof(unsigned long long)));
   TZ_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   p->own_stream = true;
   *out = guard.release();
@@ -1335,7 +1335,7 @@ int tz_timing_enable(tz_problem* p, int enable) {
         p->ev_pool[k].push_back({a, b});
       }
   TZ_HIP(hipStreamSynchronize(p->stream));
-  TZ_HIP(hipMemset(p->work_buf.p, 0, 2 * sizeof(unsigned long long)));
+  TZ_HIP(hipMemset(p->work_buf.p, 0, 3 * sizeof(unsigned long long)));
   for (int k = 0; k < K_COUNT; ++k) { p->t_ms[k] = 0; p->t_count[k] = 0; }
   return TZ_OK;
 }
@@ -1348,13 +1348,14 @@ int tz_timing_get(tz_problem* p, int kernel, double* total_ms, int64_t* launches
   return TZ_OK;
 }
 
-int tz_ipm_work_get(tz_problem* p, int64_t* factorizations, int64_t* trajectory_solves) {
+int tz_ipm_work_get(tz_problem* p, int64_t* factorizations, int64_t* trajectory_solves, int64_t* max_factorizations_one_trajectory) {
   if (!p || !factorizations || !trajectory_solves) TZ_FAIL(TZ_ERR_INVALID, "null argument");
   TZ_HIP(hipSetDevice(p->device));
   TZ_HIP(hipStreamSynchronize(p->stream));
-  unsigned long long h[2];
+  unsigned long long h[3];
   TZ_HIP(hipMemcpy(h, p->work_buf.p, sizeof(h), hipMemcpyDeviceToHost));
   *factorizations = (int64_t)h[0]; *trajectory_solves = (int64_t)h[1];
+  if (max_factorizations_one_trajectory) *max_factorizations_one_trajectory = (int64_t)h[2];
   return TZ_OK;
 }
 

@@ -121,7 +121,9 @@ def lib():
     L.tz_timing_enable.argtypes = [vp, C.c_int]
     L.tz_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.tz_ipm_plan_info.argtypes = [vp] + [C.POINTER(C.c_int64)] * 5
-    L.tz_ipm_work_get.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.tz_ipm_work_get.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.tz_problem_plan_get.argtypes = [vp] + [C.POINTER(C.c_int32)] * 5
+    L.tz_problem_plan_get.restype = C.c_int
     L.tz_debug_fetch.argtypes = [vp, C.c_int32, C.c_int, vp, C.c_int32]
     for name in ("tz_device_count", "tz_problem_create", "tz_problem_destroy", "tz_problem_set_stream", "tz_problem_sync",
                  "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run", "tz_timing_enable", "tz_timing_get",
@@ -377,9 +379,9 @@ class Problem:
         return ms.value, cnt.value
 
     def work_get(self):
-        a, b = C.c_int64(0), C.c_int64(0)
-        check(lib().tz_ipm_work_get(self._h, C.byref(a), C.byref(b)), "tz_ipm_work_get")
-        return dict(factorizations=a.value, trajectory_solves=b.value)
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().tz_ipm_work_get(self._h, C.byref(a), C.byref(b), C.byref(c)), "tz_ipm_work_get")
+        return dict(factorizations=a.value, trajectory_solves=b.value, max_factorizations_one_trajectory=c.value)
 
     def plan_info(self):
         a, b, i, c, d = (C.c_int64(0) for _ in range(5))

@@ -446,7 +446,10 @@ class TZDDPC(object):
         are equilibrated, violations of 5 ... 70 occur in the first steps of a transient and on any plant that differs from the
         model, and a push that large erases the slack information of the start; with the cap the settings that are best on the
         identified centre are also (near) best on the example's true plant (measured with the plain-C restatement under tests, both plants: double integrator N=20
-        0.83 -> 0.46-0.51 factorisations per step in the driver window, N=40 0.95 -> 0.45-0.49)."""
+        0.83 -> 0.46-0.51 factorisations per step in the driver window, N=40 0.95 -> 0.45-0.49).  Round 4 tried caps below 0.01 (0.003 is 8 %
+        fewer factorisations from the centre of X0) and a score with the worst trajectory in it: the small caps let one jittered start in
+        fifty fall back to a cold retry (jittered-start window 27.5 -> 21.3 M steps/s: a launch lasts as long as its slowest trajectory),
+        and the worst trajectory of a loop on the identified centre does not predict the worst on the true plant; not adopted."""
         nat = self._native
         if mode == "auto" and os.environ.get("TZ_WARM_GAIN"):                     # experiment switch (tools/): same range as the setter
             mode = (float(os.environ["TZ_WARM_GAIN"]), float(os.environ.get("TZ_WARM_CAP", "inf")))
