@@ -389,6 +389,30 @@ def test_closed_loop_configs_against_c_oracle(built, case, Bn, T):
     np.testing.assert_allclose(dev["u"], ref["u"], rtol=0, atol=REL * su)
 
 
+@pytest.mark.parametrize("case,Bn,T", [("pulley_n10", 4096, 6), ("dim5_n20", 1024, 5), ("dim5m2_n20", 1024, 4),
+                                       ("di_n5", 2048, 8), ("di_n10", 2048, 8), ("di_n20", 2048, 6), ("di_n40", 2048, 4), ("di_n80", 2048, 2)])
+def test_baseline_configs_at_their_full_per_gpu_batch(built, case, Bn, T):
+    """Every BASELINE.json configuration at the number of trajectories ONE GPU carries in it (config 3: 4096; config 4: 8192 / 8 = 1024,
+    with the reference's one input and with two inputs as BASELINE states it; config 5: 16384 / 8 = 2048 per horizon), the first steps
+    of the closed loop from X0 -- the transient, where the interior point works hardest -- against the plain-C oracle: every state and
+    input of every trajectory, 1e-6 (the face-optimum two-input problem: first-step value and the priced coordinate, see
+    test_closed_loop_configs_against_c_oracle).  The 8-GPU halves of configs 4 / 5 are eight independent copies of this."""
+    from tzddpc_amd.dist import vertex_noise
+    ctl, (A, B, zon) = common.gpu_controller(case)
+    noise = vertex_noise(zon.W.compute_vertices(), 0, Bn, T)
+    x0 = np.tile(zon.X0.center, (Bn, 1))
+    dev = ctl.simulate_batch(x0, noise, A, B)
+    ref = common.c_oracle_for(ctl).simulate_batch(x0, noise, A, B, threads=16)
+    assert dev["x"].shape == (Bn, T + 1, A.shape[0])
+    assert (dev["status"] == 0).all() and (ref["status"] == 0).all()
+    if case in common.NONUNIQUE:
+        np.testing.assert_allclose(dev["cost"][:, 0], ref["cost"][:, 0], rtol=1e-7)
+        np.testing.assert_allclose(dev["x"][:, 1:, 1], ref["x"][:, 1:, 1], rtol=0, atol=5e-2)
+        return
+    np.testing.assert_allclose(dev["x"], ref["x"], rtol=0, atol=REL * (1 + np.abs(ref["x"]).max()))
+    np.testing.assert_allclose(dev["u"], ref["u"], rtol=0, atol=REL * (1 + np.abs(ref["u"]).max()))
+
+
 @pytest.mark.parametrize("case", ["di_n5", "di_n10", "di_n20", "di_n40", "di_n80"])
 def test_horizon_sweep_against_c_oracle(built, case):
     """BASELINE config 5 (complexity-scaling reproduction): the same closed loop at N = 5 .. 80 on the device and in the plain-C
