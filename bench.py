@@ -166,7 +166,8 @@ def cpu_baseline(ctl, A, B, zon, label, warmup, steps, full_steps=0, seconds_bud
     from tzddpc_amd.builder import horizon_shift
     from tzddpc_amd.dist import vertex_noise
     pol = int(ctl.warm_shift_policy)       # same warm-start policy as the device chose at build time (the shift maps are data handed to the oracle)
-    co = COracle(ctl.qp, shift_policy=pol, shift_maps=horizon_shift(ctl.qp) if pol else None, warm_gain=float(getattr(ctl, "warm_push_gain", 1.0)), warm_cap=float(getattr(ctl, "warm_push_cap", 1e300)), mu_factor=float(getattr(ctl, "mu_factor", 1e-3)))
+    co = COracle(ctl.qp, shift_policy=pol, shift_maps=horizon_shift(ctl.qp) if pol else None, warm_gain=float(getattr(ctl, "warm_push_gain", 1.0)), warm_cap=float(getattr(ctl, "warm_push_cap", 1e300)), mu_factor=float(getattr(ctl, "mu_factor", 1e-3)),
+                 stored_start=(None if getattr(ctl, "stored_start", None) is None else ctl.stored_start[0]))
     budget = cpu_budget()
     max_thr = max(1, min(budget["usable_cpus"], COracle.max_threads()))
     Wv = zon.W.compute_vertices()
@@ -629,6 +630,7 @@ def main(argv=None):
                                    f"vertex-of-W noise PCG64(1000+i), all {K} timed steps in one launch",
                        "name": args.config, "trajectories_per_gpu": Bl, "horizon": horizon, "k0": k0, "nz": ctl.qp.nz, "rows": int(nat.mi),
                        "ipm_factorizations_per_trajectory_step": iters_mean, "ipm_factorizations_slowest_trajectory": int(head["fmax"][med]), "warm_start": os.environ.get("TZ_WARM", "1") != "0",
+                       "stored_start": (None if getattr(ctl, "stored_start", None) is None else [float(v) for v in ctl.stored_start[0]]),
                        "warm_shift_policy": int(ctl.warm_shift_policy), "warm_push_gain": float(ctl.warm_push_gain), "warm_push_cap": (None if not np.isfinite(ctl.warm_push_cap) else float(ctl.warm_push_cap)), "mu_factor": float(ctl.mu_factor), "unsolved_trajectory_steps": head["nbad"],
                        "gathered_rows": int(head["gathered"].shape[0]), "world_size_read_back": (dist.get_world_size() if use_dist else 1),
                        "lds_bytes_per_workgroup": nat.plan_info()["lds_bytes"],

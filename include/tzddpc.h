@@ -278,6 +278,15 @@ int tz_mpc_step(tz_problem* p, int32_t B, double* x, double* xbar, double* e, co
 int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, double* e, const double* w,
                const double* A_true, const double* B_true, double* u_out, double* cost, int32_t* status);
 
+/* Stored start.  Solves the problem once, cold, for the parameters (xbar0, e0) (host pointers, n doubles each; typically the centre of
+ * X0 and e0 = 0: where every closed loop of the reference's examples begins, examples/1.double_integrator_sim.py:62-70) and keeps
+ * the solution and its multipliers with the handle.  From then on the first step of a closed loop that has no previous solution
+ * (a fresh tz_simulate_batch, the first tz_mpc_step / tz_mpc_run after tz_problem_reset_warm) starts every trajectory from that
+ * point -- a warm start like any other: same optimum, fewer iterations (13 -> 0 ... 5 for the double integrator N = 20) -- instead of
+ * from the cold point.  tz_solve_batch is not affected (always cold).  NULL pointers forget the stored start.  Fails (nothing
+ * stored) when the reference point itself is not solvable. */
+int tz_problem_store_start(tz_problem* p, const double* xbar0, const double* e0);
+
 /* Warm-start shift policy of the closed-loop entry points: 0 never (default), 1 every warm-started step, k >= 2 only the steps
  * that follow a step of at least k interior-point iterations (the transient) and, after those, for as long as the shifted steps
  * finish in one iteration (up to tz_problem_set_warm_quiet of them).  Which one pays depends on the problem (double

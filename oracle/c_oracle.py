@@ -25,7 +25,7 @@ class Desc(C.Structure):
                 ("CK", _dp), ("DK", _dp), ("K", _dp), ("pmax", C.c_int32), ("absCK", _dp), ("absKCK", _dp), ("power", _ip),
                 ("max_iter", C.c_int32), ("tol", C.c_double), ("reg", C.c_double), ("step_frac", C.c_double),
                 ("warm_floor", C.c_double), ("warm_gain", C.c_double), ("warm_cap", C.c_double), ("mu_tol", C.c_double), ("res_tol", C.c_double), ("aff_thr", C.c_double), ("aff_mu", C.c_double),
-                ("shift_var", _ip), ("shift_row", _ip), ("shift_policy", C.c_int32), ("shift_quiet", C.c_int32)]
+                ("shift_var", _ip), ("shift_row", _ip), ("shift_policy", C.c_int32), ("shift_quiet", C.c_int32), ("start_xbar0", _dp)]
 
 
 def _cpu_tag() -> str:
@@ -75,7 +75,7 @@ def lib():
 
 
 class COracle:
-    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999, warm_floor=1e-8, warm_gain=1.0, warm_cap=1e300, mu_factor=1e-3, res_factor=100.0, aff_thr=0.99, aff_mu=1e-3, shift_policy=0, shift_maps=None, shift_quiet=16):
+    def __init__(self, qp, max_iter=40, tol=1e-10, reg=1e-12, step_frac=0.99999, warm_floor=1e-8, warm_gain=1.0, warm_cap=1e300, mu_factor=1e-3, res_factor=100.0, aff_thr=0.99, aff_mu=1e-3, shift_policy=0, shift_maps=None, shift_quiet=16, stored_start=None):
         self.qp = qp
         self._keep = []
         d = Desc()
@@ -105,6 +105,8 @@ class COracle:
             d.shift_var = self._pin(np.ascontiguousarray(sv, dtype=np.int32)).ctypes.data_as(_ip)
             d.shift_row = self._pin(np.ascontiguousarray(sr, dtype=np.int32)).ctypes.data_as(_ip)
         d.shift_policy = int(shift_policy)
+        if stored_start is not None:            # closed loops begin from the solution at this point (e0 = 0), as the device with tz_problem_store_start
+            d.start_xbar0 = self._pin(np.ascontiguousarray(stored_start, dtype=np.float64).reshape(qp.n)).ctypes.data_as(_dp)
         self.d = d
 
     def _pin(self, a):

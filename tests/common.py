@@ -179,4 +179,6 @@ def c_oracle_for(ctl, **kw):
     kw.setdefault("warm_gain", float(getattr(ctl, "warm_push_gain", 1.0)))
     kw.setdefault("mu_factor", float(getattr(ctl, "mu_factor", 1e-3)))
     kw.setdefault("warm_cap", float(getattr(ctl, "warm_push_cap", 1e300)))
+    ss = getattr(ctl, "stored_start", None)                       # fresh closed loops begin from the stored start on both sides
+    kw.setdefault("stored_start", None if ss is None else ss[0])
     return COracle(ctl.qp, shift_policy=pol, shift_maps=horizon_shift(ctl.qp) if pol else None, **kw)

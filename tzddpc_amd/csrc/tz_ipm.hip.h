@@ -11,6 +11,7 @@
 #pragma once
 
 #define TZ_MINWAVES 4
+#define TZ_SEED_VIOL_MAX 0.1     // stored start: largest violation of the new rows (equilibrated) it is still used at
 // H lives in LDS as tile rows of quads (4 column tiles); a quad is 4 matrix rows of 16 doubles padded to TZ_QROW = 17 so
 // that neither the MFMA accumulator access (row-major inside the quad) nor the column access of the factorisation and the
 // triangular solves runs into LDS bank conflicts (row stride 16 doubles = 32 banks collides 4- to 8-way).
@@ -1035,7 +1036,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   __syncthreads();
 
   const int nsteps = fused ? F0.nsteps : 1;
-  int was_shifted = (p.shift_policy >= 2 && p.warm != 0) ? p.shift_state[b] : 0;
+  int was_shifted = (p.warm != 0 && (p.shift_policy >= 2 || p.shift_state[b] == -2)) ? p.shift_state[b] : 0;
   int status = 1, it = 0;
   int work_f = 0, work_s = 0;                // uniform: kept in scalar registers
   int rpar = 0;                              // which exchange buffer the next block reduction uses
@@ -1068,7 +1069,12 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   // took one Newton step in EVERY step from the 17th quiet step on -- 0.51 factorisations per step in steps 30-130 of the headline
   // problem instead of 0.01.)
   bool shifted = false;
-  if (src != 0) {
+  const bool seeded = src != 0 && was_shifted == -2;
+  if (seeded) {
+    // the stored start (tz_problem_store_start) IS a solution for the start of the loop: taken as it is, and counted as the first
+    // quiet step of the shifted regime (a loop that begins with a step of 0 iterations would otherwise never enter it)
+    was_shifted = (pk.shift_policy >= 2) ? 1 : 0;
+  } else if (src != 0) {
     const int prev_it = (step == 0) ? pk.iters[b] : it;
     const bool quiet_run = was_shifted > 0 && prev_it <= 1;
     const int nquiet = quiet_run ? was_shifted : 0;                       // was_shifted - 1 quiet steps so far, this one included: was_shifted
@@ -1191,12 +1197,18 @@ retry_solve:
     TZ_COLS(c, nz) scq = fmax(scq, fabs(qv[c]));
     tz_block_reduce3<RED_MAXU, RED_MAXU, RED_MAXU>(viol, scq, sch, red, rpar);      // also the scales of the stopping test
     TZ_STAMP(PH_WARM_B);
+    // the stored start is ONE reference solve shared by all trajectories: a trajectory whose new rows it violates by more than
+    // TZ_SEED_VIOL_MAX (equilibrated units) is far from the reference point and starts cold -- measured on jittered starts of the double
+    // integrator (C oracle): below 0.1 the stored start needs 3-9 iterations, above 0.4 it needs 13-21, more than the 13 of a cold start
+    if (seeded && viol > TZ_SEED_VIOL_MAX) { warm = false; TZ_ROWS(k, r) l_[k] = 1.0; }
+    else {
     const double sig = fmin(fmax(pk.warm_floor, pk.warm_gain * viol), pk.warm_cap);
     const double sig2 = sig * sig;
     TZ_ROWS(k, r) {                  // slack >= sig, multiplier >= sig^2 / slack: onto the central path of mu = sig^2 where the pair was
       s_[k] = fmax(TZ_H(k, r) - TZ_GX(k, r), sig);           // below it; an inactive row keeps its multiplier ~ 0 instead of being
       l_[k] = fmax(l_[k], sig2 * tz_recip(s_[k]));           // lifted to sig (which alone set mu ~ sig * mean slack: 6 more iterations)
       vin[r] = l_[k];                                        // staged for the stopping test of the starting point (exact_rd at it == 0)
+    }
     }
   }
   if (!warm) {

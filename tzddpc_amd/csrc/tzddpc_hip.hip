@@ -189,6 +189,8 @@ struct tz_problem {
   int lastB = 0;
   bool prof = false;
   bool have_prev = false; int prevB = 0;   // x / s / lambda of the previous closed-loop step are valid for prevB trajectories
+  DevBuf<double> ref_x, ref_lam;          // stored start (tz_problem_store_start): solution and multipliers of one reference solve
+  bool have_ref = false;
   double warm_floor = 1e-8, warm_gain = 1.0, warm_cap = 1e300, mu_factor = 1e-3, res_factor = 100.0, aff_thr = 0.99, aff_mu = 1e-3;
   bool warm_enabled = true;
   int ntube = 0;
@@ -1178,6 +1180,51 @@ int tz_solve_batch(tz_problem* p, int32_t B, const double* xbar0, const double* 
   return TZ_OK;
 }
 
+// Stored start: the first closed-loop step of a trajectory that has no previous solution starts from the solution of ONE reference
+// solve (tz_problem_store_start: the caller's point, typically the centre of X0 with e0 = 0) instead of from the cold point.
+__global__ void tz_seed_kernel(int B, int nz, int mi, const double* rx, const double* rl, double* x, double* lam, int* prev_status, int* iters, int* shift_state) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)B * nz) x[i] = rx[i % nz];
+  if (i < (size_t)B * mi) lam[i] = rl[i % mi];
+  if (i < (size_t)B) { prev_status[i] = 0; iters[i] = 0; shift_state[i] = -2; }      // -2: stored start (tz_ipm_kernel: taken unshifted, then the shifted regime)
+}
+static int seed_warm(tz_problem* p, int B) {
+  const size_t total = (size_t)B * std::max(p->nz, p->mi);
+  hipLaunchKernelGGL(tz_seed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream, B, p->nz, p->mi, p->ref_x.p, p->ref_lam.p,
+                     p->x.p, p->lam.p, p->prev_status.p, p->iters.p, p->shift_state.p);
+  TZ_HIP(hipGetLastError());
+  p->have_prev = true; p->prevB = B;
+  return TZ_OK;
+}
+// warm-start state of a closed-loop launch: the previous step's, else the stored start's, else none (cold)
+static int closed_loop_warm(tz_problem* p, int B, bool* warm) {
+  *warm = p->warm_enabled && p->have_prev && p->prevB == B;
+  if (!*warm && p->warm_enabled && p->have_ref) { int rc = seed_warm(p, B); if (rc) return rc; *warm = true; }
+  return TZ_OK;
+}
+
+int tz_problem_store_start(tz_problem* p, const double* xbar0, const double* e0) {
+  if (!p) TZ_FAIL(TZ_ERR_INVALID, "null problem");
+  if (!xbar0 || !e0) { p->have_ref = false; return TZ_OK; }                       // NULL: forget the stored start
+  TZ_HIP(hipSetDevice(p->device));
+  int rc = ensure_workspace(p, 1);
+  if (rc) return rc;
+  TZ_HIP(hipMemcpyAsync(p->in_x0.p, xbar0, (size_t)p->n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  TZ_HIP(hipMemcpyAsync(p->in_e0.p, e0, (size_t)p->n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  rc = launch_solve(p, 1, p->in_x0.p, p->in_e0.p, p->v.p, p->xbar.p, p->cost.p, p->status.p, p->iters.p, nullptr);
+  if (rc) return rc;
+  int st = -1;
+  TZ_HIP(hipMemcpyAsync(&st, p->status.p, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  TZ_HIP(hipStreamSynchronize(p->stream));
+  if (st != 0) TZ_FAIL(TZ_ERR_INVALID, "the reference point is not solvable (status %d): no start stored", st);
+  TZ_HIP(p->ref_x.alloc((size_t)p->nz)); TZ_HIP(p->ref_lam.alloc((size_t)p->mi));
+  TZ_HIP(hipMemcpyAsync(p->ref_x.p, p->x.p, (size_t)p->nz * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  TZ_HIP(hipMemcpyAsync(p->ref_lam.p, p->lam.p, (size_t)p->mi * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  TZ_HIP(hipStreamSynchronize(p->stream));
+  p->have_ref = true; p->have_prev = false;
+  return TZ_OK;
+}
+
 int tz_mpc_step(tz_problem* p, int32_t B, double* x, double* xbar, double* e, const double* w,
                 const double* A_true, const double* B_true, double* u_out, double* cost, int32_t* status) {
   if (!p || !x || !xbar || !e || !w || !A_true || !B_true || !cost || !status) TZ_FAIL(TZ_ERR_INVALID, "null argument");
@@ -1185,7 +1232,8 @@ int tz_mpc_step(tz_problem* p, int32_t B, double* x, double* xbar, double* e, co
   TZ_HIP(hipSetDevice(p->device));
   int rc = ensure_workspace(p, B);
   if (rc) return rc;
-  const bool warm = p->warm_enabled && p->have_prev && p->prevB == B;
+  bool warm = false;
+  if ((rc = closed_loop_warm(p, B, &warm))) return rc;
   if (p->fuse_enabled) {
     rc = launch_step_fused(p, B, x, xbar, e, w, (size_t)p->n, A_true, B_true, u_out, (size_t)p->m, nullptr, 0, cost, 1, status, nullptr, warm);
     if (rc == TZ_OK) { p->have_prev = true; p->prevB = B; }
@@ -1207,7 +1255,8 @@ int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, dou
   if (rc) return rc;
   TZ_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int), p->stream));
   if (p->fuse_enabled) {                    // all K steps of every trajectory in ONE launch: the state never leaves the workgroup
-    const bool warm = p->warm_enabled && p->have_prev && p->prevB == B;
+    bool warm = false;
+    if ((rc = closed_loop_warm(p, B, &warm))) return rc;
     rc = launch_step_fused(p, B, x, xbar, e, w, (size_t)p->n, A_true, B_true, u_out, (size_t)p->m, nullptr, 0,
                            cost, 1, p->status.p, status, warm, K, StepStrides{(size_t)B * p->n, 0, 0, 0});
     if (rc) return rc;
@@ -1215,7 +1264,8 @@ int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, dou
     return TZ_OK;
   }
   for (int t = 0; t < K; ++t) {
-    const bool warm = p->warm_enabled && p->have_prev && p->prevB == B;
+    bool warm = false;
+    if ((rc = closed_loop_warm(p, B, &warm))) return rc;
     rc = launch_solve(p, B, xbar, e, p->v.p, p->xbar.p, cost, p->status.p, p->iters.p, nullptr, 1, warm, true);
     if (rc) return rc;
     p->have_prev = true; p->prevB = B;
@@ -1257,14 +1307,16 @@ int tz_simulate_batch(tz_problem* p, int32_t B, int32_t T, const double* x0, con
   TZ_HIP(hipMemcpyAsync(p->st_xbar.p, p->st_x.p, (size_t)B * n * sizeof(double), hipMemcpyDeviceToDevice, st));   // xbar = x0 (:69)
   TZ_HIP(hipMemsetAsync(p->st_e.p, 0, (size_t)B * n * sizeof(double), st));                                        // e = 0   (:70)
   TZ_HIP(hipMemsetAsync(p->sticky.p, 0, (size_t)B * sizeof(int), st));
+  bool warm0 = false;                                                     // a fresh loop: the stored start if there is one, else cold
+  if ((rc = closed_loop_warm(p, B, &warm0))) return rc;
   if (p->fuse_enabled) {
     rc = launch_step_fused(p, B, p->st_x.p, p->st_xbar.p, p->st_e.p, dnoise, (size_t)T * n, dA, dB,
                            du, (size_t)T * m, dx + n, (size_t)(T + 1) * n,
-                           dcost, (size_t)T, p->status.p, p->sticky.p, false, T, StepStrides{(size_t)n, (size_t)m, (size_t)n, 1});
+                           dcost, (size_t)T, p->status.p, p->sticky.p, warm0, T, StepStrides{(size_t)n, (size_t)m, (size_t)n, 1});
     if (rc) return rc;
   }
   for (int t = 0; t < T && !p->fuse_enabled; ++t) {
-    rc = launch_solve(p, B, p->st_xbar.p, p->st_e.p, p->v.p, p->xbar.p, dcost + t, p->status.p, p->iters.p, nullptr, (size_t)T, p->warm_enabled && t > 0, true);
+    rc = launch_solve(p, B, p->st_xbar.p, p->st_e.p, p->v.p, p->xbar.p, dcost + t, p->status.p, p->iters.p, nullptr, (size_t)T, p->warm_enabled && (t > 0 || warm0), true);
     if (rc) return rc;
     rc = launch_plant(p, B, dA, dB, dnoise + (size_t)t * n, (size_t)T * n, p->v.p, p->xbar.p, p->status.p,
                       p->st_x.p, p->st_xbar.p, p->st_e.p, du + (size_t)t * m, (size_t)T * m,

@@ -109,6 +109,8 @@ def lib():
     for nm in ("tz_problem_attach_tube_stack", "tz_genstack_create", "tz_genstack_destroy", "tz_genstack_intervals", "tz_genstack_values", "tz_genstack_info"):
         getattr(L, nm).restype = C.c_int
     L.tz_problem_reset_warm.argtypes = [vp]
+    L.tz_problem_store_start.argtypes = [vp, vp, vp]
+    L.tz_problem_store_start.restype = C.c_int
     L.tz_problem_attach_tube_stack.argtypes = [vp, vp]
     L.tz_problem_attach_tube_stack.restype = C.c_int
     L.tz_problem_set_stopping.argtypes = [vp, C.c_double, C.c_double]
@@ -135,7 +137,7 @@ def lib():
     return L
 
 
-EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy", "tz_problem_plan_get",
+EXPORTED_SYMBOLS = ("tz_abi_version", "tz_last_error", "tz_device_count", "tz_problem_create", "tz_problem_destroy", "tz_problem_plan_get", "tz_problem_store_start",
                     "tz_problem_set_stream", "tz_problem_sync", "tz_solve_batch", "tz_simulate_batch", "tz_mpc_step", "tz_mpc_run",
                     "tz_timing_enable", "tz_timing_get", "tz_ipm_plan_info", "tz_ipm_work_get", "tz_debug_fetch",
                     "tz_problem_set_warm_shift", "tz_problem_set_stopping", "tz_problem_set_warm_quiet", "tz_problem_set_warm_push", "tz_problem_reset_warm", "tz_identify_batch", "tz_specrad_batch", "tz_adversary_batch",
@@ -291,6 +293,7 @@ class Problem:
         check(L.tz_problem_create(int(device), C.byref(d), C.byref(h)), "tz_problem_create")
         self._h = h
         self.device = int(device)
+        self.stored_start = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -366,6 +369,16 @@ class Problem:
     def set_warm_push(self, floor: float = 1e-8, gain: float = 1.0, cap: float = 1e300):
         check(lib().tz_problem_set_warm_push(self._h, float(floor), float(gain), float(min(cap, 1e300))), "tz_problem_set_warm_push")
         self.warm_push = (float(floor), float(gain), float(cap))
+
+    def store_start(self, xbar0=None, e0=None):
+        """Solve once at (xbar0, e0) and start fresh closed loops from that solution (``tz_problem_store_start``); None forgets it."""
+        if xbar0 is None:
+            check(lib().tz_problem_store_start(self._h, None, None), "tz_problem_store_start")
+            self.stored_start = None
+            return
+        a = _f64(xbar0).reshape(self.n); b = _f64(np.zeros(self.n) if e0 is None else e0).reshape(self.n)
+        check(lib().tz_problem_store_start(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)), "tz_problem_store_start")
+        self.stored_start = (a.copy(), b.copy())
 
     def set_warm_shift(self, policy: int):
         check(lib().tz_problem_set_warm_shift(self._h, int(policy)), "tz_problem_set_warm_shift")

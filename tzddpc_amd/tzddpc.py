@@ -300,6 +300,20 @@ class TZDDPC(object):
         self.warm_shift_policy = self._choose_warm_shift(warm_shift, A, B)
         self.warm_push_gain, self.warm_push_cap = self._choose_warm_push(warm_gain, A, B)
         self.mu_factor = self._choose_mu_factor(mu_factor, A, B)
+        # stored start (round 4): fresh closed loops begin from the solution at the centre of X0 with e0 = 0 -- where the loops of the
+        # reference's examples begin (examples/1.double_integrator_sim.py:62-70: x0 = X0.sample(), xbar = x0, e = 0) -- instead of
+        # from the cold point; "off" / None keeps the cold start, a pair (xbar0, e0) stores another point.  Skipped when that point is
+        # not solvable (an X0 whose centre is infeasible) and for literal / cutting-plane problems (their steps are separate launches).
+        self.stored_start = None
+        ss = solver_kwargs.pop("stored_start", "auto" if calibrate else "off")
+        if ss not in ("off", None, False) and stack is None:
+            pt = (np.asarray(self.zonotopes.X0.center, float), np.zeros(n)) if ss == "auto" else (np.asarray(ss[0], float), np.asarray(ss[1], float))
+            try:
+                self._native.store_start(*pt)
+                self.stored_start = pt
+            except native.NativeError:
+                if ss != "auto":
+                    raise
         self.calibration_seconds = time.perf_counter() - t0       # ~31 closed loops of 24 x 48 steps when everything is "auto"
         self.calibrated = dict(warm_shift=warm_shift == "auto", warm_push=warm_gain == "auto", mu_factor=mu_factor == "auto")
         self.problem_full = self._native
