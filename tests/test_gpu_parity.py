@@ -302,6 +302,35 @@ def test_warm_started_closed_loop_equals_cold(built):
     np.testing.assert_allclose(tx.cpu().numpy(), xs[:, -1], atol=1e-6)
 
 
+@pytest.mark.parametrize("case", ["pulley_n10", "di_n20"])
+def test_split_launches_continue_where_the_first_one_stopped(built, case):
+    """tz_mpc_run called twice (5 + 20 steps) is the same closed loop as one call of 25 steps: the second launch starts warm from the
+    first one's last step -- not from the stored start again, not cold (round 4: the stored start's mark survived the first launch of
+    problems without a shift policy and sent their trajectories back to a cold start; same states, 6 % more factorisations)."""
+    import torch
+    from tzddpc_amd.dist import vertex_noise
+    ctl, (A, B, zon) = common.gpu_controller(case)
+    nat = ctl._native; n, m = ctl.qp.n, ctl.qp.m
+    Bn, T = 256, 25
+    dev = torch.device("cuda", 0)
+    noise = torch.from_numpy(np.ascontiguousarray(vertex_noise(zon.W.compute_vertices(), 0, Bn, T).transpose(1, 0, 2))).to(dev)
+    At = torch.from_numpy(np.ascontiguousarray(A)).to(dev); Bt = torch.from_numpy(np.ascontiguousarray(B).reshape(n, m)).to(dev)
+    out = {}
+    for name, cuts in (("one", (25,)), ("two", (5, 20))):
+        x = torch.from_numpy(np.tile(zon.X0.center, (Bn, 1))).to(dev); xbar = x.clone(); e = torch.zeros_like(x)
+        u = torch.zeros((Bn, m), dtype=torch.float64, device=dev); cost = torch.zeros(Bn, dtype=torch.float64, device=dev)
+        st = torch.zeros(Bn, dtype=torch.int32, device=dev)
+        nat.reset_warm(); nat.timing_enable(True)
+        t0 = 0
+        for k in cuts:
+            nat.mpc_run_ptr(Bn, k, x.data_ptr(), xbar.data_ptr(), e.data_ptr(), noise[t0].data_ptr(), At.data_ptr(), Bt.data_ptr(), u.data_ptr(), cost.data_ptr(), st.data_ptr())
+            nat.sync(); assert int((st != 0).sum()) == 0
+            t0 += k
+        out[name] = (x.cpu().numpy().copy(), nat.work_get()["factorizations"]); nat.timing_enable(False)
+    np.testing.assert_allclose(out["two"][0], out["one"][0], rtol=0, atol=REL * (1 + np.abs(out["one"][0]).max()))
+    assert out["two"][1] <= 1.01 * out["one"][1] + Bn, (out["two"][1], out["one"][1])        # (+ one per trajectory: G x is formed afresh at a launch's first step)
+
+
 def test_fused_step_equals_four_kernel_step(built):
     """The one-launch closed-loop step (tube + parameter maps + interior point + recovery + plant inside tz_ipm_kernel) and the
     four-kernel sequence used by tz_solve_batch do the same arithmetic."""

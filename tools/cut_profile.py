@@ -81,7 +81,8 @@ def main():
     os.makedirs(out, exist_ok=True)
     flags = ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc", "-mllvm", "-greedy-regclass-priority-trumps-globalness=1", "-mllvm", "-disable-machine-licm"]
     procs = []
-    for k in list(CUTS) + list(ITER_CUTS):
+    only = [int(a) for a in sys.argv[1:]]                          # optional: only these checkpoints
+    for k in [k for k in list(CUTS) + list(ITER_CUTS) if not only or k in only]:
         base = f"{TMP}{k}"
         d = os.path.join(base, "tzddpc_amd", "csrc")                      # the source includes ../../include/tzddpc.h
         shutil.rmtree(base, ignore_errors=True); shutil.copytree(SRC, d); shutil.copytree(os.path.join(ROOT, "include"), os.path.join(base, "include"))

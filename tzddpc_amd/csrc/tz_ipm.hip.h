@@ -1491,7 +1491,7 @@ retry_solve:
     TZ_ROWS(k, r) { pe.s[(size_t)b * mi + r] = s_[k]; pe.lam[(size_t)b * mi + r] = l_[k]; }
     if (t == 0) {
       pe.status[b] = status; pe.iters[b] = it;
-      if (pe.shift_policy >= 2) pe.shift_state[b] = was_shifted;
+      pe.shift_state[b] = was_shifted;             // (also without a shift policy: a stored start's mark -2 must not survive the launch)
       if (pe.status_copy) pe.status_copy[b] = status;
       if (pe.work) { atomicAdd(pe.work, (unsigned long long)work_f); atomicAdd(pe.work + 1, (unsigned long long)work_s); atomicMax(pe.work + 2, (unsigned long long)work_f); }
     }
