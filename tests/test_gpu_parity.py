@@ -1327,6 +1327,64 @@ def test_random_points_against_the_oracle_only_chain(built, case, npts):
     assert checked >= npts // 2, checked
 
 
+_POINT_JOB = {}
+
+
+def _oracle_chain_point(i):
+    """Worker of the pool below (forked: sees _POINT_JOB; numpy only, one BLAS thread, never touches the GPU)."""
+    j = _POINT_JOB
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(1):
+            sol = j["mg"].solve_point(j["s"], j["idn"], j["N"], j["k0"], j["loss"], j["cons"], j["x0"][i], j["e0"][i])
+    except AssertionError:
+        return None
+    return float(sol["cost"]), np.asarray(sol["v"][0], float), np.asarray(sol["xbar"][1], float)
+
+
+@pytest.mark.parametrize("case,npts", [("di_n20", 1024)])
+def test_full_batch_of_points_against_the_oracle_only_chain(built, case, npts):
+    """The FORMULATION at BASELINE's batch size, not only the solver: 1024 operating points -- every trajectory's own point of
+    X0 + U(-0.25, 0.25)^n (the jittered starts of the bench, seed 7) with a tube-sized error e0 -- solved by the device in one
+    `solve_batch` and, one by one, by the oracle's own chain (oracle.collapsed: uncondensed xbar, component epigraphs, built per
+    point from the numeric (xbar0, e0); oracle.qp_ipm with its KKT certificate <= 1e-9; nothing of the product in the expected
+    values), on a pool of forked CPU workers.  Objective 1e-7, consumed input and state 1e-6; draws the oracle cannot certify are
+    skipped, the device must not report a solved point the oracle certifies infeasible."""
+    import multiprocessing as mp
+    from tests.test_oracle_golden import _make_golden
+    mg = _make_golden()
+    ctl, g, (A, B, zon) = _ctl_from_golden(case)
+    sysname, loss, cons, N, k0 = mg.CASES[case]
+    s, u, x, idn = mg.identified(sysname)
+    np.testing.assert_array_equal(x, g["data_x"])
+    n = A.shape[0]
+    rng = np.random.default_rng(7)
+    x0 = np.tile(zon.X0.center, (npts, 1)) + rng.uniform(-0.25, 0.25, size=(npts, n))
+    e0 = 0.02 * rng.standard_normal((npts, n))
+    out = ctl.solve_batch(x0, e0)
+    _POINT_JOB.update(mg=mg, s=s, idn=idn, N=N, k0=k0, loss=loss, cons=cons, x0=x0, e0=e0)
+    try:
+        workers = max(1, min(16, len(os.sched_getaffinity(0))))
+        with mp.get_context("fork").Pool(workers) as pool:
+            sols = pool.map(_oracle_chain_point, range(npts), chunksize=8)
+    finally:
+        _POINT_JOB.clear()
+    checked = 0
+    worst = [0.0, 0.0, 0.0]
+    for b, sol in enumerate(sols):
+        if sol is None:
+            continue
+        cost, v0, xb1 = sol
+        assert out["status"][b] == 0, (b, out["status"][b])
+        worst[0] = max(worst[0], abs(out["cost"][b] - cost) / (1 + abs(cost)))
+        worst[1] = max(worst[1], np.abs(out["v"][b, 0] - v0).max() / (1 + np.abs(v0).max()))
+        worst[2] = max(worst[2], np.abs(out["xbar"][b, 1] - xb1).max() / (1 + np.abs(xb1).max()))
+        checked += 1
+    print(f"{case}: {checked} of {npts} points certified by the oracle chain; worst relative gaps cost {worst[0]:.2e} v0 {worst[1]:.2e} xbar1 {worst[2]:.2e}")
+    assert checked >= (3 * npts) // 4, checked
+    assert worst[0] <= 1e-7 and worst[1] <= REL and worst[2] <= REL, worst
+
+
 @pytest.mark.parametrize("n,m,N,k0,seed", [(3, 2, 6, None, 1), (6, 3, 5, None, 2), (8, 4, 4, None, 3), (3, 2, 8, 2, 4), (1, 1, 6, None, 5), (7, 1, 5, 1, 6),
                                             (12, 5, 4, None, 7), (16, 8, 3, None, 8), (10, 2, 5, 1, 9)])
 def test_random_systems_at_odd_sizes_against_the_oracle_only_chain(built, n, m, N, k0, seed):

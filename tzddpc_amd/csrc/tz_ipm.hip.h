@@ -1036,6 +1036,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   __syncthreads();
 
   const int nsteps = fused ? F0.nsteps : 1;
+  if (fused && F0.sticky_fresh != 0 && t == 0 && F0.plant.sticky) F0.plant.sticky[b] = 0;     // this launch owns the first-failure record (read back by the same thread)
   int was_shifted = (p.warm != 0 && (p.shift_policy >= 2 || p.shift_state[b] == -2)) ? p.shift_state[b] : 0;
   int status = 1, it = 0;
   int work_f = 0, work_s = 0;                // uniform: kept in scalar registers

@@ -201,6 +201,7 @@ struct FuseParams {
   int on;
   int lean_epilogue;                // xbar[1] depends on v[0] only and v is a scaled copy of x (no equality elimination): the recovery and the plant
                                     // update of a step that reports no cost / v / xbar are done by one wave without workgroup barriers
+  int sticky_fresh;                 // the launch starts a run: plant.sticky is cleared by the kernel (no memset dispatch in front of it)
   int npar, ntheta;
   int nsteps, warm_steps;           // closed-loop steps done by this launch; warm_steps: step k+1 starts from the solution of step k
   size_t w_step, u_step, x_step, cost_step;   // element offsets per step into plant.w / plant.u_out / plant.x_out / fin.cost

@@ -311,12 +311,12 @@ struct StepStrides { size_t w, u, x, cost; };     // element offsets per closed-
 int launch_step_fused(tz_problem* p, int B, double* d_x, double* d_xbar, double* d_e, const double* d_w, size_t w_stride,
                       const double* d_A, const double* d_Bm, double* d_u, size_t u_stride, double* d_xout, size_t x_stride,
                       double* d_cost, size_t cost_stride, int* d_status, int* d_sticky, bool warm,
-                      int nsteps = 1, StepStrides ss = StepStrides{0, 0, 0, 0}) {
+                      int nsteps = 1, StepStrides ss = StepStrides{0, 0, 0, 0}, bool sticky_fresh = false) {
   p->lastB = B;
   Timer tm(p, K_IPM);
   IpmParams ip = ipm_params(p, B, d_status, p->iters.p, warm, true);
   FuseParams& F = ip.F;
-  F.on = 1; F.npar = p->npar; F.ntheta = p->ntheta; F.lean_epilogue = p->lean_epilogue ? 1 : 0;
+  F.on = 1; F.npar = p->npar; F.ntheta = p->ntheta; F.lean_epilogue = p->lean_epilogue ? 1 : 0; F.sticky_fresh = sticky_fresh ? 1 : 0;
   F.nsteps = nsteps; F.warm_steps = p->warm_enabled ? 1 : 0; ip.warm_steps = F.warm_steps;
   F.w_step = ss.w; F.u_step = ss.u; F.x_step = ss.x; F.cost_step = ss.cost;
   F.tube = TubeParams{B, p->n, p->m, p->N, p->pmax, p->ntheta, p->CKpow.p, p->Ttube.p, p->power.p, d_xbar, d_e, nullptr, nullptr};
@@ -1253,16 +1253,16 @@ int tz_mpc_run(tz_problem* p, int32_t B, int32_t K, double* x, double* xbar, dou
   TZ_HIP(hipSetDevice(p->device));
   int rc = ensure_workspace(p, B);
   if (rc) return rc;
-  TZ_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int), p->stream));
   if (p->fuse_enabled) {                    // all K steps of every trajectory in ONE launch: the state never leaves the workgroup
     bool warm = false;
     if ((rc = closed_loop_warm(p, B, &warm))) return rc;
     rc = launch_step_fused(p, B, x, xbar, e, w, (size_t)p->n, A_true, B_true, u_out, (size_t)p->m, nullptr, 0,
-                           cost, 1, p->status.p, status, warm, K, StepStrides{(size_t)B * p->n, 0, 0, 0});
+                           cost, 1, p->status.p, status, warm, K, StepStrides{(size_t)B * p->n, 0, 0, 0}, true);   // `status` cleared by the kernel
     if (rc) return rc;
     p->have_prev = true; p->prevB = B;
     return TZ_OK;
   }
+  TZ_HIP(hipMemsetAsync(status, 0, (size_t)B * sizeof(int), p->stream));
   for (int t = 0; t < K; ++t) {
     bool warm = false;
     if ((rc = closed_loop_warm(p, B, &warm))) return rc;
