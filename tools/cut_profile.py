@@ -76,6 +76,31 @@ def patched(k):
     return s
 
 
+# what-if variants of a phase (timing only: the results are wrong, the instruction stream is the same), VARIANT=<name> in the environment;
+# the libraries are then called cut<k>_<name>.so
+_GRAM_FLAG = [   # the step number reaches tz_gram_rows through the (otherwise null) profiling pointer: what-if only in the steps that are timed
+    ("tz_gram(p, Hq, Pq, vin, kl, (PROF && t == 0) ? acc_ph : nullptr)", "tz_gram(p, Hq, Pq, vin, kl, (unsigned long long*)(size_t)((fused && step >= 30) ? 1 : 0))"),
+    ("  unsigned long long tq0 = pacc ? __builtin_amdgcn_s_memtime() : 0;\n  const int lane = tz_tid() & 63;\n  const int k = lane >> 4, blk",
+     "  unsigned long long tq0 = 0; const bool whatif = pacc != nullptr; pacc = nullptr;\n  const int lane = tz_tid() & 63;\n  const int k = lane >> 4, blk"),
+]
+VARIANTS = {
+    # every Gram operand load of a wave hits one of two patch rows: the loads stay (pinned), their addresses are always in L1
+    "gram_l1": _GRAM_FLAG + [("    const char* prow = gp + (size_t)kc * rowbytes;\n#pragma unroll\n    for (int J = 0; J < R1; ++J) st.v[J]",
+                              "    const char* prow = gp + (size_t)(whatif ? (kc & 1) : kc) * rowbytes;\n#pragma unroll\n    for (int J = 0; J < R1; ++J) st.v[J]")],
+    # no operand loads at all: what the matrix instructions, masks and the fold cost by themselves
+    "gram_nold": _GRAM_FLAG + [("    for (int J = 0; J < R1; ++J) st.v[J] = tz_ld_pinned((const double*)(prow + (unsigned)(J < Tz ? J : Tz) * 128u));   // tile Tz is zero",
+                                "    for (int J = 0; J < R1; ++J) { if (whatif) st.v[J] = st.w + (double)J; else st.v[J] = tz_ld_pinned((const double*)(prow + (unsigned)(J < Tz ? J : Tz) * 128u)); }")],
+}
+
+
+def apply_variant(s):
+    v = os.environ.get("VARIANT")
+    for a, b in VARIANTS.get(v, []):
+        assert s.count(a) == 1, (v, a[:50], s.count(a))
+        s = s.replace(a, b)
+    return s
+
+
 def main():
     out = os.path.join(ROOT, "tzddpc_amd", "lib", "ab")
     os.makedirs(out, exist_ok=True)
@@ -83,12 +108,12 @@ def main():
     procs = []
     only = [int(a) for a in sys.argv[1:]]                          # optional: only these checkpoints
     for k in [k for k in list(CUTS) + list(ITER_CUTS) if not only or k in only]:
-        base = f"{TMP}{k}"
+        base = f"{TMP}{k}{os.environ.get('VARIANT', '')}"
         d = os.path.join(base, "tzddpc_amd", "csrc")                      # the source includes ../../include/tzddpc.h
         shutil.rmtree(base, ignore_errors=True); shutil.copytree(SRC, d); shutil.copytree(os.path.join(ROOT, "include"), os.path.join(base, "include"))
-        open(os.path.join(d, "tz_ipm.hip.h"), "w").write(patched(k))
+        open(os.path.join(d, "tz_ipm.hip.h"), "w").write(apply_variant(patched(k)))
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DTZ_ONLY_SMALL"] + flags + \
-              ["-I", os.path.join(ROOT, "include"), "-o", os.path.join(out, f"cut{k}.so"), os.path.join(d, "tzddpc_hip.hip")]
+              ["-I", os.path.join(ROOT, "include"), "-o", os.path.join(out, f"cut{k}" + ("_" + os.environ["VARIANT"] if os.environ.get("VARIANT") else "") + ".so"), os.path.join(d, "tzddpc_hip.hip")]
         procs.append((k, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
         if len(procs) % 4 == 0:
             for kk, pr in procs[-4:]:

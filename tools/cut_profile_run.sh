@@ -27,5 +27,5 @@ t30, t130 = loop(30), loop(130)
 print(f"{sys.argv[1]}: 30 steps {t30:.4f} ms, 130 steps {t130:.4f} ms -> {(t130 - t30) / 100 * 1e3:.3f} us per steady-state step")
 PY
 }
-for k in ${CUTS:-1 2 3 4 5 6 7 8 9 10 11 12 13 14 16}; do run tzddpc_amd/lib/ab/cut$k.so "checkpoint $k"; done
-run "$1" "full step"
+for k in ${CUTS:-1 2 3 4 5 6 7 8 9 10 11 12 13 14 16}; do run tzddpc_amd/lib/ab/cut$k${SUFFIX}.so "checkpoint $k${SUFFIX}"; done
+[ -n "$1" ] && run "$1" "full step"
