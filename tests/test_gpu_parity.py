@@ -1327,6 +1327,76 @@ def test_random_points_against_the_oracle_only_chain(built, case, npts):
     assert checked >= npts // 2, checked
 
 
+def _figure_controller(m, f, penalised):
+    """Device controller for the run of the reference's stored double-integrator figure (tests/refdi.py): the model centre, gain and
+    tube magnitudes read off the figure replace what `build_zonotopes_theta` identified from our own data set; N = 2."""
+    from tests import refdi
+    from tzddpc_amd import TZDDPC, Theta, SystemZonotopes, Zonotope, cplite as cp
+    from tzddpc_amd.harness import generate_trajectories, system
+    from tzddpc_amd.zonotope import boxed_matrix_zonotope
+    A, B, zon, T = system("di_sim")
+    zon = SystemZonotopes(zon.X0, zon.U, Zonotope(0.5 * (refdi.X_LOW + refdi.X_HIGH), np.diag(0.5 * (refdi.X_HIGH - refdi.X_LOW))), zon.W)
+    ctl = TZDDPC(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, np.random.default_rng(25)))
+    Ah, Bh, CK, DK, DD, K = refdi.model_matrices(m, f)
+    ctl.build_zonotopes_theta(zon, theta=Theta(K, np.zeros_like(A), np.zeros_like(B)))
+    ctl.Mdata = boxed_matrix_zonotope(np.hstack([Ah, Bh]), DD)
+    ctl.MdataK = boxed_matrix_zonotope(CK, DK)
+    ctl.Mdelta = boxed_matrix_zonotope(np.zeros((2, 3)), DD)
+
+    def loss_on_v(v, xb1):
+        return cp.norm(xb1[0, :], p=2) ** 2 + 1e-2 * cp.norm(v[0], p=1) + 1e-2 * cp.norm(v[1], p=1)
+    if penalised:
+        ctl.build_problem_simplified(2, 2, loss_on_v, common.nocons)
+    else:
+        ctl.build_problem(2, common.loss_di, common.nocons)
+    return ctl, (A, B, zon)
+
+
+@pytest.mark.parametrize("penalised", [False, True])
+def test_device_reproduces_the_reference_figure_run(built, penalised):
+    """The reference's stored double-integrator figure (examples/figures/double_integrator.pdf; tests/refdi.py) on the DEVICE: at the
+    reference's own twelve operating points `solve_batch` returns the inputs the reference applied -- to 5e-7 in the four steps where
+    tightened tube rows are active (stage-1 input tube on both sides, input bound, stage-1 state tube), with the predicted offset
+    0.01 / (2 Bhat'Bhat) in the steps without active rows under the committed formulation, to 1e-4 everywhere with the penalty on
+    v -- then the closed loop on the reference's disturbances (`simulate_batch`), and `Ze[1]` against the drawn polygons."""
+    from tests import refdi
+    g = refdi.vectors()
+    m = refdi.recover_model_and_inputs(g)
+    f = refdi.fit_tube_constants(g, m)
+    ctl, (A, B, zon) = _figure_controller(m, f, penalised)
+    out = ctl.solve_batch(f["xbar"][:12], f["e"], want_active=True)
+    assert (out["status"] == 0).all(), out["status"]
+    u = f["e"] @ f["K"] + out["v"][:, 0, 0]
+    d = u - m["u"]
+    assert np.abs(d[:4]).max() <= refdi.TOL_ACTIVE, d[:4]
+    np.testing.assert_allclose(out["xbar"][:4, 1], f["xbar"][1:5], atol=refdi.TOL_ACTIVE)
+    if penalised:
+        assert np.abs(d).max() <= refdi.TOL_LOOP, d
+        np.testing.assert_allclose(out["xbar"][:, 1], f["xbar"][1:13], atol=refdi.TOL_LOOP)
+    else:
+        np.testing.assert_allclose(d[[4, 6, 7, 8, 9, 10, 11]], -refdi.l1_offset(m), atol=refdi.TOL_LOOP)
+    # closed loop of examples/1.double_integrator_sim.py:75-90 on the recovered disturbances
+    sim = ctl.simulate_batch(g["x"][:1], m["w"][None], A, B)
+    assert (sim["status"] == 0).all()
+    if penalised:
+        np.testing.assert_allclose(sim["x"][0], g["x"], atol=refdi.TOL_LOOP)
+        np.testing.assert_allclose(sim["u"][0, :, 0], m["u"], atol=refdi.TOL_LOOP)
+    else:
+        np.testing.assert_allclose(sim["x"][0, :5], g["x"][:5], atol=refdi.TOL_ACTIVE)
+        np.testing.assert_allclose(sim["u"][0, :4, 0], m["u"][:4], atol=refdi.TOL_ACTIVE)
+    # Ze[1] of every solve as the device exports it (reference :377), moved by xbar[1] and reduced as the example draws it
+    if penalised:
+        from tzddpc_amd import Zonotope
+        ze = ctl.ze1_batch(f["xbar"][:12], f["e"], out["v"][:, 0])
+        for t in range(12):
+            Z = (Zonotope(ze[t][:, 0], ze[t][:, 1:]) + out["xbar"][t, 1])
+            Z = Z.reduce(min(3, int(np.asarray(Z.generators).shape[1] / 2)))
+            V = Z.polygon_vertices()
+            R = g["polygons"][t + 1]
+            np.testing.assert_allclose([V[:, 0].min(), V[:, 0].max(), V[:, 1].min(), V[:, 1].max()],
+                                       [R[:, 0].min(), R[:, 0].max(), R[:, 1].min(), R[:, 1].max()], atol=refdi.TOL_LOOP)
+
+
 _POINT_JOB = {}
 
 
