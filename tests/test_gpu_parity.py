@@ -1375,6 +1375,9 @@ def test_device_reproduces_the_reference_figure_run(built, penalised):
         np.testing.assert_allclose(out["xbar"][:, 1], f["xbar"][1:13], atol=refdi.TOL_LOOP)
     else:
         np.testing.assert_allclose(d[[4, 6, 7, 8, 9, 10, 11]], -refdi.l1_offset(m), atol=refdi.TOL_LOOP)
+    if not penalised:                # the reference's gain over the reference's model box, by the reference's test, radii on the device (tz_specrad_batch)
+        from tzddpc_amd.gain import is_gain_robust
+        assert is_gain_robust(ctl.Mdata, f["K"], 0.05, 0.99, rng=np.random.default_rng(3), device=0)
     # closed loop of examples/1.double_integrator_sim.py:75-90 on the recovered disturbances
     sim = ctl.simulate_batch(g["x"][:1], m["w"][None], A, B)
     assert (sim["status"] == 0).all()

@@ -62,6 +62,19 @@ def test_tube_formula_explains_the_polygon_sizes(fig):
     np.testing.assert_allclose(c[1:], g["x"][:-1] @ Ah.T + np.outer(m["u"], Bh[:, 0]), atol=5e-8)
     # ... and equals xbar_{t+1} + CK e_t with the recovered nominal chain
     np.testing.assert_allclose(c[1:], f["xbar"][1:] + f["e"] @ CK.T, atol=5e-8)
+    # the recovered box behaves like the Mdata of tzddpc/tzddpc.py:81-83, :119-128: the true plant lies inside it (the data-driven
+    # guarantee), the box of MdataK obeys the interval bound of Mdata [I; K], and the reference's gain (its LMI / CCP synthesis,
+    # tzddpc/utils.py:13-129) stabilises every vertex of the box -- by the reference's own test (`is_gain_robust`, :105-129), on samples
+    import itertools
+    from tzddpc_amd.gain import is_gain_robust
+    from tzddpc_amd.zonotope import boxed_matrix_zonotope
+    M0 = np.hstack([Ah, Bh])
+    assert np.all(np.abs(np.hstack([refdi.A_TRUE, refdi.B_TRUE[:, None]]) - M0) <= DD)
+    assert np.all(DK[0] <= DD[0, :2] + DD[0, 2] * np.abs(K[0]) + 1e-9)
+    worst = max(np.abs(np.linalg.eigvals(M[:, :2] + M[:, 2:] @ K)).max()
+                for M in (M0 + np.array(sg, float).reshape(2, 3) * DD for sg in itertools.product((1, -1), repeat=6)))
+    assert worst < 0.7, worst
+    assert is_gain_robust(boxed_matrix_zonotope(M0, DD), K, 0.05, 0.99, rng=np.random.default_rng(3))
 
 
 def _oracle_model(m, f):
