@@ -27,7 +27,10 @@ struct IpmItem { int I0, q0, nq, kptr, klen; };
 // order (seg[o] = first lane | lanes << 16).  An entry is ONE 16-byte record (value, byte offset of the input entry, pad): one
 // vector-memory instruction and one address add per non-zero (the kernel is issue-bound, not byte-bound: 10-byte (value, 16-bit
 // index) pairs in two arrays cost two loads and a shift-add; a 4-byte value dictionary cost three LDS gathers and was slower still).
-struct TzEll { int L, VL; const TzEllEnt* ent; const int* seg; };      // TzEllEnt, tz_d2, tz_ell_off: tz_kernels.hip.h
+// The problems with more than 64 variables (tile-triangle class) keep the COMPACT form instead -- 8-byte values and 16-bit indices in two
+// arrays, 10 bytes per non-zero: their products are paced by the rate at which G arrives from L2 (1-2 MB per pass, six passes per
+// iteration), and 16-byte records cost them 10 % (DI N = 80) to 14 % (5-dim, two inputs) of the kernel time (profiles/r4w_ab_r3_vs_r4.txt).
+struct TzEll { int L, VL; const TzEllEnt* ent; const int* seg; const double* val; const unsigned short* idx; };      // TzEllEnt, tz_d2, tz_ell_off: tz_kernels.hip.h
 // one virtual lane's walk over its L records, NL lanes apart.  base: wave-uniform address of record 0 of lane 0 of the pass (scalar
 // registers, advanced by scalar adds); lo: this lane's byte offset (one 32-bit vector register): no vector address arithmetic per load
 typedef __attribute__((address_space(1))) const char* tz_gptr;
@@ -56,6 +59,19 @@ __device__ inline double tz_ell_walk(const char* base_, unsigned lo, int L, unsi
     base += stride;
     a0 += r.x * *reinterpret_cast<const double*>(b + tz_ell_off(r.y));
   }
+  return a0 + a1;
+}
+
+// compact form: entry e of the lane at val[e * NL], idx[e * NL] (the caller offsets the pointers to the lane)
+__device__ inline double tz_ell_walk_c(const double* val, const unsigned short* idx, int L, int NL, const double* in) {
+  double a0 = 0.0, a1 = 0.0;
+  int e = 0;
+  for (; e + 3 < L; e += 4) {
+    const double x0 = val[(size_t)e * NL], x1 = val[(size_t)(e + 1) * NL], x2 = val[(size_t)(e + 2) * NL], x3 = val[(size_t)(e + 3) * NL];
+    const int i0 = idx[(size_t)e * NL], i1 = idx[(size_t)(e + 1) * NL], i2 = idx[(size_t)(e + 2) * NL], i3 = idx[(size_t)(e + 3) * NL];
+    a0 += x0 * in[i0]; a1 += x1 * in[i1]; a0 += x2 * in[i2]; a1 += x3 * in[i3];
+  }
+  for (; e < L; ++e) a0 += val[(size_t)e * NL] * in[idx[(size_t)e * NL]];
   return a0 + a1;
 }
 
@@ -306,10 +322,13 @@ __device__ inline double tz_gemvT_get3(const double* part, int nzp, int c) {
 // out[k] = (G in)_r for the rows r = t + 256 k this thread owns; `in` (nz entries) and pl (eg.VL doubles) in LDS.  Two halves: every
 // thread walks its virtual lanes (tz_ell_gemv_walk; pl must not be in use by the owners of an earlier product), and after a workgroup
 // barrier the owner of a row adds its lanes' partial sums (tz_ell_gemv_sum).
+template <bool COMPACT>
 __device__ inline void tz_ell_gemv_walk(const IpmParams& p, const double* in, double* pl) {
   const int t = tz_tid(), L = p.eg.L;
-  for (int v0 = 0; v0 < p.eg.VL; v0 += TZ_THREADS)
-    pl[v0 + t] = tz_ell_walk(reinterpret_cast<const char*>(p.eg.ent + (size_t)v0 * L), (unsigned)t * 16u, L, TZ_THREADS * 16u, in);
+  for (int v0 = 0; v0 < p.eg.VL; v0 += TZ_THREADS) {
+    if constexpr (COMPACT) pl[v0 + t] = tz_ell_walk_c(p.eg.val + (size_t)v0 * L + t, p.eg.idx + (size_t)v0 * L + t, L, TZ_THREADS, in);
+    else pl[v0 + t] = tz_ell_walk(reinterpret_cast<const char*>(p.eg.ent + (size_t)v0 * L), (unsigned)t * 16u, L, TZ_THREADS * 16u, in);
+  }
 }
 template <int MAXR>
 __device__ inline void tz_ell_gemv_sum(const double* pl, const int (&rseg)[MAXR], double (&out)[MAXR]) {
@@ -323,21 +342,24 @@ __device__ inline void tz_ell_gemv_sum(const double* pl, const int (&rseg)[MAXR]
     out[k] = a;
   }
 }
-template <int MAXR>
+template <int MAXR, bool COMPACT>
 __device__ inline void tz_ell_gemv(const IpmParams& p, const double* in, double* pl, const int (&rseg)[MAXR], double (&out)[MAXR]) {
   __syncthreads();                                   // pl may still be read by the owners of the previous product
-  tz_ell_gemv_walk(p, in, pl);
+  tz_ell_gemv_walk<COMPACT>(p, in, pl);
   __syncthreads();
   tz_ell_gemv_sum<MAXR>(pl, rseg, out);
 }
 
 // Partial sums of G'in by the 192 threads of waves 1-3 (the caller keeps wave 0 out); `in` (mi entries), pl (et.VL doubles) in
 // LDS.  After the next workgroup barrier tz_ell_colsum(pl, cseg) is column c's value for the thread holding cseg = et.seg[c].
+template <bool COMPACT>
 __device__ inline void tz_ell_gemvT_part(const IpmParams& p, const double* in, double* pl) {
   constexpr int NL = TZ_THREADS - 64;
   const int l = tz_tid() - 64, L = p.et.L;
-  for (int v0 = 0; v0 < p.et.VL; v0 += NL)
-    pl[v0 + l] = tz_ell_walk(reinterpret_cast<const char*>(p.et.ent + (size_t)v0 * L), (unsigned)l * 16u, L, NL * 16u, in);
+  for (int v0 = 0; v0 < p.et.VL; v0 += NL) {
+    if constexpr (COMPACT) pl[v0 + l] = tz_ell_walk_c(p.et.val + (size_t)v0 * L + l, p.et.idx + (size_t)v0 * L + l, L, NL, in);
+    else pl[v0 + l] = tz_ell_walk(reinterpret_cast<const char*>(p.et.ent + (size_t)v0 * L), (unsigned)l * 16u, L, NL * 16u, in);
+  }
 }
 __device__ inline double tz_ell_colsum(const double* pl, int cseg) {
   double a = 0.0;
@@ -1120,7 +1142,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     }
     if (bad) flag[1] = 1;
     TZ_ROWS(k, r) TZ_SET_H(k, r, csr_row(F.hmap, r, thl));
-    if (walk_early) tz_ell_gemv_walk(p, xv, pl);         // (pl: last read before the barriers above)
+    if (walk_early) tz_ell_gemv_walk<TT>(p, xv, pl);         // (pl: last read before the barriers above)
   } else {
     TZ_COLS(c, nzp) qv[c] = (c < nz) ? pk.q[(size_t)b * nz + c] : 0.0;
     TZ_ROWS(k, r) TZ_SET_H(k, r, pk.h[(size_t)b * mi + r]);
@@ -1143,7 +1165,7 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
     }
     TZ_STAMP(PH_RD_A);
     if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part);     // P x by wave 0 (stays in `part` for the objective)
-    else tz_ell_gemvT_part(p, vin, pl);                                   // G'lambda by waves 1-3
+    else tz_ell_gemvT_part<TT>(p, vin, pl);                                   // G'lambda by waves 1-3
     __syncthreads();
     TZ_STAMP(PH_RD_B);
     double e1 = 0.0;
@@ -1191,7 +1213,7 @@ retry_solve:
       }
     }
     if (walk_early && !retried) { tz_ell_gemv_sum<MAXR>(pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }     // walked in the prologue
-    else if (src != 2 || retried) { tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
+    else if (src != 2 || retried) { tz_ell_gemv<MAXR, TT>(p, xv, pl, rseg_, gx_); if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; } }
     TZ_STAMP(PH_WARM_A);
     double viol = 0.0;
     TZ_ROWS(k, r) { const double hv = TZ_H(k, r); viol = fmax(viol, TZ_GX(k, r) - hv); sch = fmax(sch, fabs(hv)); }
@@ -1221,7 +1243,7 @@ retry_solve:
     __syncthreads();
     TZ_ROWS(k, r) vin[r] = TZ_H(k, r);
     __syncthreads();
-    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
+    if (!wave0) tz_ell_gemvT_part<TT>(p, vin, pl);
     __syncthreads();
     if (t < nzp) r1v[t] = (t < nz) ? tz_ell_colsum(pl, cseg) - qv[t] : 0.0;
     __syncthreads();
@@ -1231,7 +1253,7 @@ retry_solve:
     else okf = tz_cholesky(p, Hq, dinv, flag);
     if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, xv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, xv);
     }
-    tz_ell_gemv<MAXR>(p, xv, pl, rseg_, gx_);
+    tz_ell_gemv<MAXR, TT>(p, xv, pl, rseg_, gx_);
     if (PARK) { TZ_ROWS(k, r) gL[r] = gx_[k]; }
   }
   if (!warm) {
@@ -1323,7 +1345,7 @@ retry_solve:
         tz_cholesky_wave(p, Hq, dinv, flag, flag + 2);
         __builtin_amdgcn_s_setprio(0);
       } else {
-        tz_ell_gemvT_part(p, vin, pl);
+        tz_ell_gemvT_part<TT>(p, vin, pl);
         tz_gemvT_partial<NCG, 1, 3>(p.P, p.nP, nzp, xv, part2);
         // the three waves meet on a counter (wave 0 is busy factoring); wave 1 then assembles the right-hand side and runs the
         // forward substitution one tile column behind the factorisation
@@ -1348,7 +1370,7 @@ retry_solve:
       TZ_STAMP(PH_CHOL);
     } else {
       if (wave0) tz_gemvT_partial<NCG, 0, 1>(p.P, p.nP, nzp, xv, part2);
-      else tz_ell_gemvT_part(p, vin, pl);
+      else tz_ell_gemvT_part<TT>(p, vin, pl);
       __syncthreads();
       TZ_COLS(c, nzp) {
         const double pxq = (c < nz) ? part2[c] + qv[c] : 0.0;
@@ -1374,7 +1396,7 @@ retry_solve:
     else if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, have_y ? tmpz : r1v, dxv, have_y); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
-    tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
+    tz_ell_gemv<MAXR, TT>(p, dxv, pl, rseg_, g_);
     TZ_STAMP(PH_GEMV);
     __builtin_amdgcn_s_setprio(TZ_PRIO_ELEM);
     // step to the boundary: alpha = 1 / max(1, max_i(-dv_i / v_i))
@@ -1421,7 +1443,7 @@ retry_solve:
     __syncthreads();
     TZ_STAMP(PH_ELEM);
     __builtin_amdgcn_s_setprio(0);
-    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
+    if (!wave0) tz_ell_gemvT_part<TT>(p, vin, pl);
     __syncthreads();
     TZ_COLS(c, nzp) r1v[c] = (c < nz) ? -rdv[c] - tz_ell_colsum(pl, cseg) : 0.0;
     __syncthreads();
@@ -1430,7 +1452,7 @@ retry_solve:
     else if (p.chol1) tz_chol_solve_wave(p, Hq, dinv, r1v, dxv); else tz_chol_solve(p, Hq, dinv, r1v, tmpz, dxv);
     __syncthreads();
     TZ_STAMP(PH_SOLVE);
-    tz_ell_gemv<MAXR>(p, dxv, pl, rseg_, g_);
+    tz_ell_gemv<MAXR, TT>(p, dxv, pl, rseg_, g_);
     TZ_STAMP(PH_GEMV);
     __builtin_amdgcn_s_setprio(TZ_PRIO_ELEM);
     double ms = 0.0, ml = 0.0, z3 = 0;
@@ -1474,7 +1496,7 @@ retry_solve:
     double hy = 0.0;
     TZ_ROWS(k, r) { const double y = lm_ok ? l_[k] * il : 0.0; vin[r] = y; hy += TZ_H(k, r) * y; }
     __syncthreads();
-    if (!wave0) tz_ell_gemvT_part(p, vin, pl);
+    if (!wave0) tz_ell_gemvT_part<TT>(p, vin, pl);
     __syncthreads();
     double gmax = fabs(tz_ell_colsum(pl, cseg));
     tz_block_reduce3<RED_MAX, RED_SUM, RED_SUM, 2>(gmax, hy, z2, red, rpar);

@@ -61,10 +61,11 @@ struct DevBuf {
 
 // Balanced lane-ELL of a sparse matrix for the matrix-vector products of tz_ipm_kernel (TzEll in tz_ipm.hip.h).
 // outs[o] = (index, value) pairs of output o; NL physical lanes per pass; the virtual lane count VL is a multiple of NL.
+// compact: 8-byte values and 16-bit indices in two arrays (the tile-triangle class, see TzEll) instead of 16-byte records.
 struct DevEll {
-  DevBuf<TzEllEnt> ent; DevBuf<int> seg;
+  DevBuf<TzEllEnt> ent; DevBuf<int> seg; DevBuf<double> val; DevBuf<unsigned short> idx;
   int L = 1, VL = 0;
-  hipError_t build(const std::vector<std::vector<std::pair<int, double>>>& outs, int NL, int VLwant) {
+  hipError_t build(const std::vector<std::vector<std::pair<int, double>>>& outs, int NL, int VLwant, bool compact) {
     VL = ((std::max(VLwant, 1) + NL - 1) / NL) * NL;
     size_t longest = 1;
     for (auto& o : outs) longest = std::max(longest, o.size());
@@ -73,7 +74,9 @@ struct DevEll {
       for (auto& o : outs) lanes += (o.size() + L - 1) / L;
       if (lanes <= (size_t)VL) break;
     }
-    std::vector<TzEllEnt> v((size_t)VL * L, TzEllEnt{0.0, 0u, 0u});
+    std::vector<TzEllEnt> v(compact ? 0 : (size_t)VL * L, TzEllEnt{0.0, 0u, 0u});
+    std::vector<double> cv(compact ? (size_t)VL * L : 0, 0.0);
+    std::vector<unsigned short> ci(compact ? (size_t)VL * L : 0, (unsigned short)0);
     std::vector<int> sg(std::max<size_t>(outs.size(), 1), 0);
     int lane = 0;
     for (size_t o = 0; o < outs.size(); ++o) {
@@ -82,16 +85,20 @@ struct DevEll {
       for (size_t e = 0; e < outs[o].size(); ++e) {
         const int vl = lane + (int)(e / L), slot = (int)(e % L);
         const size_t pos = ((size_t)(vl / NL) * L + slot) * NL + (vl % NL);
-        v[pos] = TzEllEnt{outs[o][e].second, (unsigned)outs[o][e].first * 8u, 0u};
+        if (compact) { cv[pos] = outs[o][e].second; ci[pos] = (unsigned short)outs[o][e].first; }
+        else v[pos] = TzEllEnt{outs[o][e].second, (unsigned)outs[o][e].first * 8u, 0u};
       }
       lane += cnt;
     }
     hipError_t e;
-    if ((e = ent.upload(v)) != hipSuccess) return e;
+    if (compact) {
+      if ((e = val.upload(cv)) != hipSuccess) return e;
+      if ((e = idx.upload(ci)) != hipSuccess) return e;
+    } else if ((e = ent.upload(v)) != hipSuccess) return e;
     return seg.upload(sg);
   }
-  TzEll view() const { return TzEll{L, VL, ent.p, seg.p}; }
-  void swap(DevEll& o) { ent.swap(o.ent); seg.swap(o.seg); std::swap(L, o.L); std::swap(VL, o.VL); }
+  TzEll view() const { return TzEll{L, VL, ent.p, seg.p, val.p, idx.p}; }
+  void swap(DevEll& o) { ent.swap(o.ent); seg.swap(o.seg); val.swap(o.val); idx.swap(o.idx); std::swap(L, o.L); std::swap(VL, o.VL); }
 };
 
 struct DevCsr {          // device copy of a tz_affmap (CSR in the ABI) re-laid out as ELL, see TzCsr
@@ -895,8 +902,8 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
       if (v != 0.0) { byrow[r].push_back({c, v}); bycol[c].push_back({r, v}); }
     }
     // G x: twice as many virtual lanes as rows, so the long rows can be cut up;  G'v: the 192 lanes of waves 1-3 per pass
-    TZ_HIP(p->eg.build(byrow, TZ_THREADS, 2 * mi));
-    TZ_HIP(p->et.build(bycol, TZ_THREADS - 64, std::max(TZ_THREADS - 64, 2 * nz)));
+    TZ_HIP(p->eg.build(byrow, TZ_THREADS, 2 * mi, p->tt));
+    TZ_HIP(p->et.build(bycol, TZ_THREADS - 64, std::max(TZ_THREADS - 64, 2 * nz), p->tt));
     p->nell = std::max(p->eg.VL, p->et.VL);
   }
   if (klist.empty()) klist.push_back(0);
@@ -1037,7 +1044,7 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
       if (small_built) return hipSuccess;
       std::vector<std::vector<std::pair<int, double>>> byrow((size_t)mi);
       for (int r = 0; r < mi; ++r) for (int c = 0; c < nz; ++c) { const double v = G[(size_t)r * nzp + c]; if (v != 0.0) byrow[r].push_back({c, v}); }
-      hipError_t e = eg_small.build(byrow, TZ_THREADS, mi);
+      hipError_t e = eg_small.build(byrow, TZ_THREADS, mi, p->tt);
       nell_small = std::max(eg_small.VL, p->et.VL); small_built = true;
       return e;
     };
@@ -1079,6 +1086,11 @@ int tz_problem_create(int device, const tz_problem_desc* d, tz_problem** out) {
     p->ipm_fn = ipm_kernel_for(p->maxr, p->ncg, wgs_per_cu, ttk);
   }
   if (!p->ipm_fn) TZ_FAIL(TZ_ERR_UNSUPPORTED, "this development build (TZ_ONLY_SMALL) carries only the mi <= 256, nz <= 64 kernel");
+  {                                                                     // the G x / G'v tables were built for the class decided above
+    bool ttk = false;
+    (void)ipm_kernel_for(p->maxr, p->ncg, wgs_per_cu, ttk);
+    if (ttk != p->tt) TZ_FAIL(TZ_ERR_UNSUPPORTED, "kernel class and table format disagree (development build?)");
+  }
   TZ_HIP(hipFuncSetAttribute((const void*)p->ipm_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
   if (const char* e = tz_dev_getenv("TZ_PROF")) { p->prof = (e[0] == '1'); }
   if (p->prof && !TZ_PROFILE) TZ_FAIL(TZ_ERR_INVALID, "TZ_PROF=1 needs the diagnostic build of the library (libtzddpc_hip_prof.so)");
