@@ -105,13 +105,10 @@ def build_controller(device, config, horizon=None, k0_override="keep"):
     rng = np.random.default_rng(25)
     ctl = TZDDPC(generate_trajectories(A, B, zon.X0, zon.U, zon.W, 1, T, rng), device=device)
     ctl.build_zonotopes_theta(zon)
-    kw = {"tol": float(os.environ["TZ_TOL"])} if "TZ_TOL" in os.environ else {}
-    if "TZ_STEP_FRAC" in os.environ:
-        kw["step_frac"] = float(os.environ["TZ_STEP_FRAC"])
     if k0 is None:
-        ctl.build_problem(N, loss, cons, **kw)
+        ctl.build_problem(N, loss, cons)
     else:
-        ctl.build_problem_simplified(k0, N, loss, cons, **kw)
+        ctl.build_problem_simplified(k0, N, loss, cons)
     return ctl, A, B, zon, N, k0
 
 
@@ -637,7 +634,7 @@ def main(argv=None):
             "config": {"workload": f"{desc}; {Bl} closed-loop trajectories per GPU, {'complexity-script' if sysname in ('di_cc', 'di2in') else 'example'} zonotopes, "
                                    f"vertex-of-W noise PCG64(1000+i), all {K} timed steps in one launch",
                        "name": args.config, "trajectories_per_gpu": Bl, "horizon": horizon, "k0": k0, "nz": ctl.qp.nz, "rows": int(nat.mi),
-                       "ipm_factorizations_per_trajectory_step": iters_mean, "ipm_factorizations_slowest_trajectory": int(head["fmax"][med]), "warm_start": os.environ.get("TZ_WARM", "1") != "0",
+                       "ipm_factorizations_per_trajectory_step": iters_mean, "ipm_factorizations_slowest_trajectory": int(head["fmax"][med]), "warm_start": True,
                        "stored_start": (None if getattr(ctl, "stored_start", None) is None else [float(v) for v in ctl.stored_start[0]]),
                        "warm_shift_policy": int(ctl.warm_shift_policy), "warm_push_gain": float(ctl.warm_push_gain), "warm_push_cap": (None if not np.isfinite(ctl.warm_push_cap) else float(ctl.warm_push_cap)), "mu_factor": float(ctl.mu_factor), "unsolved_trajectory_steps": head["nbad"],
                        "gathered_rows": int(head["gathered"].shape[0]), "world_size_read_back": (dist.get_world_size() if use_dist else 1),

@@ -18,7 +18,6 @@ from __future__ import annotations
 
 from typing import Callable, List, Optional, Tuple
 
-import os
 
 import numpy as np
 
@@ -465,10 +464,6 @@ class TZDDPC(object):
         fifty fall back to a cold retry (jittered-start window 27.5 -> 21.3 M steps/s: a launch lasts as long as its slowest trajectory),
         and the worst trajectory of a loop on the identified centre does not predict the worst on the true plant; not adopted."""
         nat = self._native
-        if mode == "auto" and os.environ.get("TZ_WARM_GAIN"):                     # experiment switch (tools/): same range as the setter
-            mode = (float(os.environ["TZ_WARM_GAIN"]), float(os.environ.get("TZ_WARM_CAP", "inf")))
-            if not (mode[0] >= 0.0 and mode[1] >= 1e-8):
-                raise ValueError(f"TZ_WARM_GAIN / TZ_WARM_CAP out of range: {mode}")
         if mode != "auto":
             gain, cap = (float(mode[0]), float(mode[1])) if isinstance(mode, (tuple, list)) else (float(mode), float("inf"))
         else:
@@ -489,8 +484,7 @@ class TZDDPC(object):
                     w.append(nat.work_get()["factorizations"] + (10 ** 9 if np.any(status != 0) else 0))
                     nat.timing_enable(False)
                 work[(g, c)] = w[0] - w[1]
-            if os.environ.get("TZ_CALIB_DEBUG"):
-                print("warm push calibration (factorisations):", work)
+            self.warm_push_calibration = dict(work)                     # (gain, cap) -> factorisations of the calibration loop (diagnostics)
             least = min(work.values())
             gain, cap = min((k for k in cands if work[k] <= 1.02 * least), key=lambda k: (min(k[0] * 10.0, k[1]), k[0]))   # smallest push
         nat.set_warm_push(1e-8, gain, cap)
