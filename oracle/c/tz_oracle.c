@@ -192,12 +192,15 @@ static double max_step(int n, const double* v, const double* dv) {
 /* TZO_TRACE=1: per-iteration mu / residuals / step lengths on stderr (how the warm start of round 2 was found); read once */
 static int tzo_trace(void) { static int t = -1; if (t < 0) t = getenv("TZO_TRACE") != NULL; return t; }
 
+/* what a solved step leaves for the next one (see `carry` in ipm): a breakdown -> its final level and gate; no shift at all -> forget */
+#define TZO_RLEV_GATE 1e6   /* as TZ_RLEV_GATE of the device kernel */
+#define IPM_DONE() do { if (carry && regx0 == 0.0) { if (brk > 0.0) { carry[0] = regx; carry[1] = brk; } else if (regx == 0.0) { carry[0] = 0.0; carry[1] = 0.0; } } } while (0)
 /* status: 0 solved, 1 max_iter, 2 numerical, 3 infeasible */
 /* warm != 0: x / lam hold the previous closed-loop step's solution of this trajectory; the slacks are re-derived for the
  * new h and (s, lam) pushed into the cone: sig = min(max(warm_floor, warm_gain * largest violation of the new rows), warm_cap), s >= sig,
  * lam >= sig^2 / s. */
 #define TZO_SEED_VIOL_MAX 0.1
-static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const double* h, double* x, double* s, double* lam, int* iters, double* wk, int warm, double regx0) {
+static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const double* h, double* x, double* s, double* lam, int* iters, double* wk, int warm, double regx0, double* carry) {
   /* warm == 2: as warm == 1 and gx (G x of the starting point) is still valid in the work area from the previous step;
    * warm == 3: the previous (x, lambda) moved one step along the horizon first (values move unscaled, hence the D / E ratios) */
   int nz = S->nz, mi = S->mi;
@@ -246,6 +249,11 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
   scd += 1.0; scp += 1.0;
   int it;
   double regx = regx0;               /* diagonal shift of the Newton matrix: 0, raised when a factorisation breaks down; the retry starts at 1e-6 */
+  /* carry (closed loops): [0] the shift the previous solved step ended with, [1] TZO_RLEV_GATE x the complementarity at which it first broke down.
+   * A warm-started step takes min(carry[0], 1e-6) BEFORE its factorisation fails again, from the iteration on whose mu is below
+   * carry[1] (as the device, TZ_RLEV_CARRY_MAX); brk: that multiple of mu at the first breakdown of this solve */
+  double brk = 0.0;
+  const double carry_lvl = (carry && warm) ? carry[0] : 0.0, carry_gate = (carry && warm) ? carry[1] : 0.0;
   for (it = 0; it < d->max_iter; ++it) {
     double nrd = 0, nrp = 0, mu = 0;
     for (int c = 0; c < nz; ++c) {
@@ -258,11 +266,12 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
     mu /= mi; nrd /= scd; nrp /= scp;
     *iters = it;
     if (tzo_trace()) fprintf(stderr, "  it %d mu %.3e rd %.3e rp %.3e warm %d\n", it, mu, nrd, nrp, warm);
-    if (nrd <= d->res_tol && nrp <= d->res_tol && mu <= d->mu_tol) return 0;
+    if (nrd <= d->res_tol && nrp <= d->res_tol && mu <= d->mu_tol) { IPM_DONE(); return 0; }
     if (mu <= 1e-3 * d->mu_tol && !(it == 0 && warm))       /* mu collapsed before the residuals: numerical (a warm start may BEGIN */
-      return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 2;   /* there: its first Newton step is what removes the residuals) */
+      { IPM_DONE(); return (nrd <= 1e3 * d->tol && nrp <= 1e3 * d->tol) ? 0 : 2; }   /* there: its first Newton step is what removes the residuals) */
     if (!(mu == mu) || !(nrd == nrd) || mu > 1e200) return 2;
     for (int r = 0; r < mi; ++r) w[r] = lam[r] / s[r];
+    if (regx == 0.0 && carry_lvl > 0.0 && mu <= carry_gate) regx = fmin(carry_lvl, 1e-6);
     /* Newton matrix; a factorisation that breaks down (degenerate problems late in the solve: the weights of active and inactive
      * rows are 1e18 apart and H loses definiteness in rounding) raises the diagonal shift, 1e-9, 1e-6, 1e-3, 1 -- kept for the rest
      * of the solve -- and the iteration is repeated from the same point (it counts as an iteration, as on the device).  A shifted H
@@ -270,6 +279,7 @@ static int ipm(const tzo_desc* d, const setup_t* S, const double* q, const doubl
     form_H(S, w, d->reg + regx, H, GW);
     if (!cholesky(nz, H)) {
       if (regx >= 1.0 || (regx0 == 0.0 && getenv("TZO_NO_ESCALATE"))) return 2;     /* the switch: test of the retry path alone */
+      if (brk == 0.0) brk = TZO_RLEV_GATE * mu;
       regx = regx == 0.0 ? 1e-9 : regx * 1e3;
       if (tzo_trace()) fprintf(stderr, "     factorisation failed: diagonal shift %.1e\n", regx);
       continue;
@@ -326,7 +336,7 @@ static size_t work_doubles(const tzo_desc* d, const setup_t* S) {
 }
 
 static void solve_one(const tzo_desc* d, const setup_t* S, const double* xbar0, const double* e0,
-                      double* v, double* xbar, double* cost, int32_t* status, int32_t* iters, uint8_t* active, double* wk, int warm) {
+                      double* v, double* xbar, double* cost, int32_t* status, int32_t* iters, uint8_t* active, double* wk, int warm, double* rcarry) {
   int nz = S->nz, mi = S->mi, n = d->n, m = d->m, N = d->N, nt = d->ntheta;
   double* th = wk; double* q = th + nt; double* h = q + nz; double* x = h + mi; double* s = x + nz; double* lam = s + mi;
   double* tws = lam + mi; double* iw = tws + (size_t)(d->pmax + 2) * (3 * n + m);
@@ -344,11 +354,11 @@ static void solve_one(const tzo_desc* d, const setup_t* S, const double* xbar0, 
       for (int t = 0; t < nt; ++t) a += M[r * nt + t] * th[t];
       h[k] = S->E[k] * S->sgn[k] * a;
     }
-    st = ipm(d, S, q, h, x, s, lam, &it, iw, warm, 0.0);
+    st = ipm(d, S, q, h, x, s, lam, &it, iw, warm, 0.0, rcarry);
     if (st != 0) {                      /* same safeguard as the device kernel: once more, cold, textbook fraction to the boundary */
       tzo_desc d2 = *d; int it2 = 0;
       d2.step_frac = fmin(d->step_frac, 0.99);
-      st = ipm(&d2, S, q, h, x, s, lam, &it2, iw, 0, 1e-6);      /* ... and a shifted Newton matrix from the first iteration (a breakdown the
+      st = ipm(&d2, S, q, h, x, s, lam, &it2, iw, 0, 1e-6, NULL);      /* ... and a shifted Newton matrix from the first iteration (a breakdown the
                                                                    * pivot test did not see: tiny positive pivots, garbage step) */
       it += it2;
       if (st != 0 && farkas(S, h, lam)) st = 3;
@@ -389,7 +399,7 @@ int tzo_solve_batch(const tzo_desc* d, int B, const double* xbar0, const double*
 #endif
     for (int b = 0; b < B; ++b)
       solve_one(d, S, xbar0 + (size_t)b * n, e0 + (size_t)b * n, v + (size_t)b * N * m, xbar + (size_t)b * (N + 1) * n,
-                cost + b, status + b, iters ? iters + b : NULL, active ? active + (size_t)b * d->nc : NULL, wk, 0);
+                cost + b, status + b, iters ? iters + b : NULL, active ? active + (size_t)b * d->nc : NULL, wk, 0, NULL);
     free(wk);
   }
   free_setup(S);
@@ -418,7 +428,7 @@ static int tzo_simulate_core(const tzo_desc* d, int B, int T, const double* x0, 
     wref = (double*)malloc(sizeof(double) * wd);
     double* v0 = (double*)malloc(sizeof(double) * N * m); double* xb0 = (double*)malloc(sizeof(double) * (N + 1) * n);
     double ez[16] = {0}, c0; int32_t st0, it0;
-    solve_one(d, S, d->start_xbar0, ez, v0, xb0, &c0, &st0, &it0, NULL, wref, 0);
+    solve_one(d, S, d->start_xbar0, ez, v0, xb0, &c0, &st0, &it0, NULL, wref, 0, NULL);
     if (st0 != 0) { free(wref); wref = NULL; }              /* reference point not solvable: no stored start (as the device library) */
     free(v0); free(xb0);
   }
@@ -435,7 +445,7 @@ static int tzo_simulate_core(const tzo_desc* d, int B, int T, const double* x0, 
 #pragma omp for schedule(dynamic, 4)
 #endif
     for (int b = 0; b < B; ++b) {
-      int32_t sticky = 0; int prev_ok = 0; int prev_it = 0; int was_shifted = 0;
+      int32_t sticky = 0; int prev_ok = 0; int prev_it = 0; int was_shifted = 0; double rcarry[2] = {0.0, 0.0};
       if (wref) { memcpy(wk, wref, sizeof(double) * wd); prev_ok = 1; was_shifted = -2; }     /* -2: stored start, see below */
       for (int i = 0; i < n; ++i) { x[i] = x0[(size_t)b * n + i]; xbar[i] = x[i]; e[i] = 0; x_traj[((size_t)b * (T + 1)) * n + i] = x[i]; }
       for (int t = 0; t < T; ++t) {
@@ -454,7 +464,7 @@ static int tzo_simulate_core(const tzo_desc* d, int B, int T, const double* x0, 
         if (prev_ok && S->srow && (d->shift_policy == 1 || (d->shift_policy >= 2 && (prev_it >= d->shift_policy || back || (quiet_run && (d->shift_quiet == 0 || nquiet <= d->shift_quiet)))))) wmode = 3;
         was_shifted = (wmode == 3) ? 1 + nquiet : ((prev_ok && ((quiet_run && d->shift_policy >= 2) || (was_shifted == -1 && !back))) ? -1 : 0);
         }
-        solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk, wmode);
+        solve_one(d, S, xbar, e, v, xb, &c, &st, &it, NULL, wk, wmode, rcarry);
         prev_it = it;
         if (iters_out) iters_out[(size_t)b * T + t] = it;
         prev_ok = (st == 0) && d->warm_floor > 0;

@@ -11,6 +11,10 @@
 #pragma once
 
 #define TZ_MINWAVES 4
+#define TZ_RLEV_CARRY_MAX 2      // diagonal-shift level (1e-6) a warm-started step may inherit from the step before ...
+#ifndef TZ_RLEV_GATE
+#define TZ_RLEV_GATE 1e6         // ... from the iteration on whose complementarity is within this factor of the one at which that step broke down
+#endif
 #define TZ_SEED_VIOL_MAX 0.1     // stored start: largest violation of the new rows (equilibrated) it is still used at
 // H lives in LDS as tile rows of quads (4 column tiles); a quad is 4 matrix rows of 16 doubles padded to TZ_QROW = 17 so
 // that neither the MFMA accumulator access (row-major inside the quad) nor the column access of the factorisation and the
@@ -1062,6 +1066,8 @@ __global__ __launch_bounds__(TZ_THREADS, MINW) void tz_ipm_kernel(IpmParams p) {
   int was_shifted = (p.warm != 0 && (p.shift_policy >= 2 || p.shift_state[b] == -2)) ? p.shift_state[b] : 0;
   int status = 1, it = 0;
   int work_f = 0, work_s = 0;                // uniform: kept in scalar registers
+  int rlev_carry = 0;                        // diagonal-shift level the previous solved step of this launch ended with ...
+  unsigned brk_hi = 0;                       // ... and (the high word of) TZ_RLEV_GATE x the complementarity at which it first broke down
   int rpar = 0;                              // which exchange buffer the next block reduction uses
   for (int step = 0; step < nsteps; ++step) {     // closed-loop steps of this trajectory (one when the launch is a single solve)
   // start point of this step: 0 cold, 1 the (x, lambda) stored by an earlier launch, 2 the (x, lambda) of the previous step (still
@@ -1276,7 +1282,13 @@ retry_solve:
   bool px_in_part = false;                  // `part` holds the partial sums of P x for the final x (left there by exact_rd)
   // diagonal-shift level of this solve (0: none), raised when a factorisation breaks down; the cold retry of a failed solve starts at
   // level 2 (1e-6): a breakdown the pivot test does not see (tiny positive pivots, a garbage step) is what made the first one fail
+  // ... and a warm-started step that follows a step with a breakdown takes that step's level (at most 2: 1e-6) BEFORE the
+  // factorisation fails again, from the iteration on whose complementarity is within TZ_RLEV_GATE x of the one at which the previous step broke
+  // down (earlier iterations stay unshifted: a shift from the first iteration on stalls the strictly convex two-input problem).  A
+  // trajectory on a degenerate problem (an optimal face: the two-input 5-dim system) otherwise re-discovers the breakdown in every
+  // step: three of its seven factorisations per step were such repeats.
   int rlev = retried ? 2 : 0;
+  unsigned brk_now = 0;                      // high word of TZ_RLEV_GATE x mu at the first breakdown of this solve
   __builtin_amdgcn_s_setprio(0);
   for (it = 0; it < pk.max_iter && status == 1; ++it) {
     __builtin_amdgcn_s_setprio(TZ_PRIO_ELEM);
@@ -1315,6 +1327,8 @@ retry_solve:
     TZ_ROWS(k, r) { is_[k] = tz_recip(s_[k]); il_[k] = tz_recip(l_[k]); w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
     __syncthreads();
     TZ_STAMP(PH_TOP);
+    if (rlev == 0 && rlev_carry != 0 && warm && (unsigned)__builtin_amdgcn_readfirstlane((int)tz_hi(mu)) <= brk_hi)
+      rlev = rlev_carry < TZ_RLEV_CARRY_MAX ? rlev_carry : TZ_RLEV_CARRY_MAX;
     bool okc;
     bool have_y = false;                                // tmpz holds y = inv(L) r1 (forward substitution done while factoring)
     // A factorisation that breaks down (degenerate problems late in the solve: the weights of active and inactive rows are 1e18
@@ -1385,6 +1399,7 @@ retry_solve:
     }
     if (!okc) {
       if (rlev >= 4) { status = 2; break; }
+      if (brk_now == 0) brk_now = (unsigned)__builtin_amdgcn_readfirstlane((int)tz_hi(mu * TZ_RLEV_GATE));
       rlev = __builtin_amdgcn_readfirstlane(rlev + 1);
       __syncthreads();                                 // every thread has read the failure flag
       if (t == 0) flag[0] = 0;
@@ -1474,6 +1489,10 @@ retry_solve:
   __builtin_amdgcn_s_setprio(TZ_PRIO_GLUE);       // stopping test done: recovery, plant update, tube, maps and warm start of the next step are short
   TZ_FRESH_T();
   work_f = __builtin_amdgcn_readfirstlane(work_f + it + ((warm || skip) ? 0 : 1));
+  if (status == 0 && !skip && attempt == 0) {
+    if (brk_now != 0) { rlev_carry = __builtin_amdgcn_readfirstlane(rlev); brk_hi = brk_now; }
+    else if (rlev == 0) { rlev_carry = 0; brk_hi = 0; }               // a step that needed no shift at all: forget
+  }
   if (status != 0 && !skip && attempt == 0) {
     attempt = 1; src = 0;
     __syncthreads();
