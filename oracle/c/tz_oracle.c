@@ -354,7 +354,7 @@ static void solve_one(const tzo_desc* d, const setup_t* S, const double* xbar0, 
       for (int t = 0; t < nt; ++t) a += M[r * nt + t] * th[t];
       h[k] = S->E[k] * S->sgn[k] * a;
     }
-    st = ipm(d, S, q, h, x, s, lam, &it, iw, warm, 0.0, rcarry);
+    st = ipm(d, S, q, h, x, s, lam, &it, iw, warm, 0.0, (nz > 64 || mi > 1024) ? rcarry : NULL);     /* the device's tile-triangle class */
     if (st != 0) {                      /* same safeguard as the device kernel: once more, cold, textbook fraction to the boundary */
       tzo_desc d2 = *d; int it2 = 0;
       d2.step_frac = fmin(d->step_frac, 0.99);

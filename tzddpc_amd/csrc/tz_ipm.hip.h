@@ -1282,7 +1282,7 @@ retry_solve:
   bool px_in_part = false;                  // `part` holds the partial sums of P x for the final x (left there by exact_rd)
   // diagonal-shift level of this solve (0: none), raised when a factorisation breaks down; the cold retry of a failed solve starts at
   // level 2 (1e-6): a breakdown the pivot test does not see (tiny positive pivots, a garbage step) is what made the first one fail
-  // ... and a warm-started step that follows a step with a breakdown takes that step's level (at most 2: 1e-6) BEFORE the
+  // ... and, in the class with more than 64 variables, a warm-started step that follows a step with a breakdown takes that step's level (at most 2: 1e-6) BEFORE the
   // factorisation fails again, from the iteration on whose complementarity is within TZ_RLEV_GATE x of the one at which the previous step broke
   // down (earlier iterations stay unshifted: a shift from the first iteration on stalls the strictly convex two-input problem).  A
   // trajectory on a degenerate problem (an optimal face: the two-input 5-dim system) otherwise re-discovers the breakdown in every
@@ -1327,8 +1327,10 @@ retry_solve:
     TZ_ROWS(k, r) { is_[k] = tz_recip(s_[k]); il_[k] = tz_recip(l_[k]); w_[k] = l_[k] * is_[k]; vin[r] = w_[k]; }
     __syncthreads();
     TZ_STAMP(PH_TOP);
-    if (rlev == 0 && rlev_carry != 0 && warm && (unsigned)__builtin_amdgcn_readfirstlane((int)tz_hi(mu)) <= brk_hi)
-      rlev = rlev_carry < TZ_RLEV_CARRY_MAX ? rlev_carry : TZ_RLEV_CARRY_MAX;
+    if constexpr (TT) {                      // (the problems with at most 64 variables have shown no breakdowns: the bookkeeping costs them 0.9 %)
+      if (rlev == 0 && rlev_carry != 0 && warm && (unsigned)__builtin_amdgcn_readfirstlane((int)tz_hi(mu)) <= brk_hi)
+        rlev = rlev_carry < TZ_RLEV_CARRY_MAX ? rlev_carry : TZ_RLEV_CARRY_MAX;
+    }
     bool okc;
     bool have_y = false;                                // tmpz holds y = inv(L) r1 (forward substitution done while factoring)
     // A factorisation that breaks down (degenerate problems late in the solve: the weights of active and inactive rows are 1e18
@@ -1399,7 +1401,7 @@ retry_solve:
     }
     if (!okc) {
       if (rlev >= 4) { status = 2; break; }
-      if (brk_now == 0) brk_now = (unsigned)__builtin_amdgcn_readfirstlane((int)tz_hi(mu * TZ_RLEV_GATE));
+      if constexpr (TT) { if (brk_now == 0) brk_now = (unsigned)__builtin_amdgcn_readfirstlane((int)tz_hi(mu * TZ_RLEV_GATE)); }
       rlev = __builtin_amdgcn_readfirstlane(rlev + 1);
       __syncthreads();                                 // every thread has read the failure flag
       if (t == 0) flag[0] = 0;
@@ -1489,7 +1491,7 @@ retry_solve:
   __builtin_amdgcn_s_setprio(TZ_PRIO_GLUE);       // stopping test done: recovery, plant update, tube, maps and warm start of the next step are short
   TZ_FRESH_T();
   work_f = __builtin_amdgcn_readfirstlane(work_f + it + ((warm || skip) ? 0 : 1));
-  if (status == 0 && !skip && attempt == 0) {
+  if (TT && status == 0 && !skip && attempt == 0) {
     if (brk_now != 0) { rlev_carry = __builtin_amdgcn_readfirstlane(rlev); brk_hi = brk_now; }
     else if (rlev == 0) { rlev_carry = 0; brk_hi = 0; }               // a step that needed no shift at all: forget
   }
